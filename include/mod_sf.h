@@ -1,0 +1,201 @@
+/*
+ * mod_sf.h — C ABI of the MI355X-native scene-flow + moving-point clustering path.
+ *
+ * The reference (ActiveIntelligentSystemsLab/moving_object_detector) has no FFI: the path is a ROS-1 node
+ * (scene_flow_constructor) plus a nodelet plugin (scene_flow_clusterer/scene_flow_clusterer,
+ * scene_flow_clusterer/nodelet_plugins.xml:3-4) joined by the ~scene_flow PointCloud2 topic.  This header is the
+ * boundary a maintainer binds instead of the CPU loops; every entry point cites the reference code it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the node/nodelet side of the binding.
+ *
+ * Conventions
+ *   - plain C, POD structs, no exceptions cross the boundary;
+ *   - return value: 0 = ok, >0 = "skipped, input missing" (the reference silently publishes nothing,
+ *     scene_flow_constructor/src/scene_flow_constructor.cpp:104,110,122,127,133), <0 = error
+ *     (mod_last_error() gives the text);
+ *   - a context is single-caller (the reference runs construct() on one thread at a time, :389-392, and the
+ *     clusterer on a single-threaded callback queue, clusterer_nodelet.cpp:25,35); distinct contexts are independent;
+ *   - "_dev" entry points take DEVICE pointers (HBM-resident planes) and only enqueue work on the context's
+ *     stream; "_host" entry points take host pointers, stage through the context and synchronise;
+ *   - image planes are row-major, pitch == width, frames contiguous ([frames][H][W]).
+ */
+#ifndef MOD_SF_H_
+#define MOD_SF_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOD_ABI_VERSION 1
+
+/* status codes */
+#define MOD_OK                      0
+#define MOD_SKIP_NO_DISPARITY_NOW   1  /* construct(): `if (disparity_now)` guard, scene_flow_constructor.cpp:110 */
+#define MOD_SKIP_NO_DISPARITY_PREV  2  /* :104,127 */
+#define MOD_SKIP_NO_FLOW            3  /* :122-123 */
+#define MOD_SKIP_NO_TRANSFORM       4  /* :127 (visual odometry failed, :251-255) */
+#define MOD_ERR_INVALID_ARGUMENT   -1
+#define MOD_ERR_NOT_CONFIGURED     -2  /* camera/params not set */
+#define MOD_ERR_CAPACITY           -3  /* frames / image larger than the context was created for */
+#define MOD_ERR_DEVICE             -4  /* HIP runtime error */
+#define MOD_ERR_NO_DEVICE          -5  /* no gfx950 device / library built without a usable device */
+
+typedef struct ModContext ModContext;
+
+/* Context creation parameters. */
+typedef struct ModConfig {
+  int32_t device;       /* HIP device ordinal */
+  int32_t max_width;    /* largest image width  the scratch is sized for */
+  int32_t max_height;   /* largest image height the scratch is sized for */
+  int32_t max_frames;   /* largest batch (frames per call) */
+  int32_t max_objects;  /* per-frame capacity of the ModObject output; 0 -> max_width*max_height/100 (Clusterer.cfg:8 lower bound) */
+  int32_t reserved;
+  void   *stream;       /* hipStream_t to enqueue on; NULL -> the context creates its own */
+} ModConfig;
+
+/*
+ * Camera + disparity-message constants.
+ *   fx..Ty : left CameraInfo projection matrix P (P[0],P[5],P[2],P[6],P[3],P[7]) as used by
+ *            image_geometry::PinholeCameraModel::projectPixelTo3dRay / project3dToPixel
+ *            (call sites disparity_image_processor.cpp:45, scene_flow_constructor.cpp:84);
+ *   disp_* : stereo_msgs/DisparityImage f, T, min_disparity, max_disparity
+ *            (disparity_image_processor.cpp:25-27,41-42).
+ */
+typedef struct ModCamera {
+  int32_t width, height;
+  double  fx, fy, cx, cy, Tx, Ty;
+  float   disp_f, disp_T, min_disparity, max_disparity;
+} ModCamera;
+
+/*
+ * dynamic_reconfigure parameters, read by value inside the hot loops
+ * (scene_flow_constructor/cfg/SceneFlowConstructor.cfg:8, scene_flow_clusterer/cfg/Clusterer.cfg:8-11).
+ * cluster_size must be >= 1 (the reference's range is [100,10000]).
+ */
+typedef struct ModParams {
+  int32_t dynamic_flow_diff;   /* default 5   [px]  */
+  int32_t cluster_size;        /* default 2500 [px] */
+  int32_t neighbor_distance;   /* default 4   [px], 1..MOD_MAX_NEIGHBOR_DISTANCE */
+  int32_t reserved;
+  double  depth_diff;          /* default 0.15 [m]  */
+  double  dynamic_speed;       /* default 0.3 [m/s] */
+} ModParams;
+#define MOD_MAX_NEIGHBOR_DISTANCE 16
+
+/* geometry_msgs/Transform previous->now (scene_flow_constructor.cpp:248-249,411): translation + quaternion x,y,z,w. */
+typedef struct ModTransform {
+  double t[3];
+  double q[4];
+} ModTransform;
+
+/* moving_object_msgs/MovingObject (moving_object_msgs/msg/MovingObject.msg:3-7); orientation is always (0,0,0,1). */
+typedef struct ModObject {
+  int32_t id;
+  int32_t n_points;       /* cluster size (not in the message; handy for tests/tracing) */
+  double  center[3];
+  double  orientation[4];
+  double  velocity[3];
+  double  bounding_box[3];
+} ModObject;
+
+/* The four values handed to SceneFlowConstructor::construct (scene_flow_constructor.cpp:91-97,392), batched. */
+typedef struct ModFrameBatch {
+  int32_t      frames;
+  int32_t      reserved;
+  const float *disparity_now;    /* dev [frames][H][W] 32FC1; NULL -> MOD_SKIP_NO_DISPARITY_NOW  */
+  const float *disparity_prev;   /* dev [frames][H][W] 32FC1; NULL -> MOD_SKIP_NO_DISPARITY_PREV; for a sequence D[0..F]
+                                    pass prev = D, now = D + H*W */
+  const float *flow;             /* dev [frames][H][W][2] 32FC2 (x then y, scene_flow_constructor/README.md:35-40); NULL -> skip */
+  const ModTransform *transforms;/* HOST [frames]; NULL -> MOD_SKIP_NO_TRANSFORM */
+  const double *dt;              /* HOST [frames]: stamp_now - stamp_previous in seconds (scene_flow_constructor.cpp:162-164) */
+} ModFrameBatch;
+
+/* ~scene_flow as SoA planes (+ optional reference-layout outputs). All device pointers, [frames][H][W]. */
+typedef struct ModSceneFlowPlanes {
+  float    *x, *y, *z, *vx, *vy, *vz;  /* required */
+  uint64_t *dynamic_mask;  /* optional [frames][H][mod_mask_words(W)]: bit b of word k of a row = pixel 64k+b is dynamic
+                              (calculateDynamicMap, clusterer_nodelet.cpp:40-54) */
+  void     *cloud_aos;     /* optional [frames][H][W] 32-byte pcl::PointXYZVelocity records
+                              (scene_flow_constructor/pcl_point_xyz_velocity.h:8-34: x@0 y@4 z@8 vx@16 vy@20 vz@24) */
+  float    *depth;         /* optional ~depth image (disparity_image_processor.cpp:105-120) */
+  float    *static_flow;   /* optional ~synthetic_optical_flow 32FC2 (scene_flow_constructor.cpp:65-89) */
+} ModSceneFlowPlanes;
+
+/* Output of the clusterer (clusterer_nodelet.cpp:85-95,324-343). Device pointers. */
+typedef struct ModClusterOut {
+  int32_t   *labels;      /* [frames][H][W]: -1 = none, 0..K-1 in the reference's order (removeSmallClusters, :354-393) */
+  ModObject *objects;     /* [frames][max_objects] */
+  int32_t   *n_objects;   /* [frames] accepted objects (publishMovingObjects, :324-343) */
+  int32_t   *n_clusters;  /* [frames] K = clusters surviving the size filter (may be NULL) */
+} ModClusterOut;
+
+static inline int32_t mod_mask_words(int32_t width) { return (width + 63) / 64; }
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+int  mod_abi_version(void);
+int  mod_create(const ModConfig *cfg, ModContext **out_ctx);
+void mod_destroy(ModContext *ctx);
+const char *mod_last_error(const ModContext *ctx);          /* never NULL */
+int  mod_set_camera(ModContext *ctx, const ModCamera *cam); /* stereoCallback first-frame block, scene_flow_constructor.cpp:368-375 */
+int  mod_set_params(ModContext *ctx, const ModParams *prm); /* reconfigureCB, scene_flow_constructor.cpp:401-407, clusterer_nodelet.cpp:345-352 */
+int  mod_get_camera(const ModContext *ctx, ModCamera *cam);
+int  mod_get_params(const ModContext *ctx, ModParams *prm);
+int  mod_synchronize(ModContext *ctx);                      /* wait for everything enqueued on the context's stream */
+
+/* ---- hot path, device-resident ---------------------------------------------------------------------------- */
+/* construct(): toPointCloud x2 + transformPCPreviousToNow + calculateStaticOpticalFlow + constructVelocityPC
+ * (scene_flow_constructor.cpp:91-147) as one fused kernel; also emits the dynamic mask when requested. */
+int  mod_scene_flow_dev(ModContext *ctx, const ModFrameBatch *in, const ModSceneFlowPlanes *out);
+
+/* calculateDynamicMap (clusterer_nodelet.cpp:40-54) for a cloud that did not come from mod_scene_flow_dev. */
+int  mod_dynamic_mask_dev(ModContext *ctx, int32_t frames, const float *vx, const float *vy, const float *vz,
+                          uint64_t *dynamic_mask);
+
+/* clustering() + publishMovingObjects() (clusterer_nodelet.cpp:85-95,324-343) on SoA planes.
+ * planes->dynamic_mask may be NULL (computed internally). */
+int  mod_cluster_dev(ModContext *ctx, int32_t frames, const ModSceneFlowPlanes *planes, const ModClusterOut *out);
+
+/* Both stages back to back without the PointCloud2 round trip (the mask is produced by the scene-flow kernel). */
+int  mod_process_dev(ModContext *ctx, const ModFrameBatch *in, const ModSceneFlowPlanes *planes, const ModClusterOut *out);
+
+/* pcl::toROSMsg / pcl::fromROSMsg payload conversion (scene_flow_constructor.cpp:358-361, clusterer_nodelet.cpp:226). */
+int  mod_pack_cloud_dev(ModContext *ctx, int32_t frames, const ModSceneFlowPlanes *planes, void *cloud_aos);
+int  mod_unpack_cloud_dev(ModContext *ctx, int32_t frames, const void *cloud_aos, const ModSceneFlowPlanes *planes);
+
+/* ---- host-pointer convenience (what a ROS node with host-side messages calls) ----------------------------- */
+/* One frame, host buffers in/out; any output pointer may be NULL.  Returns a skip code exactly where construct()
+ * would publish nothing.  cloud_aos: W*H*32 bytes; labels: W*H int32; objects: capacity `max_objects`. */
+int  mod_process_frame_host(ModContext *ctx,
+                            const float *disparity_now, const float *disparity_prev, const float *flow,
+                            const ModTransform *transform, double dt,
+                            void *cloud_aos, int32_t *labels,
+                            ModObject *objects, int32_t max_objects, int32_t *n_objects);
+
+/* Clusterer alone on a host PointCloud2 payload (ClustererNodelet::dataCB, clusterer_nodelet.cpp:221-242).
+ * point_step/row_step as in sensor_msgs/PointCloud2; fields x,y,z,vx,vy,vz at offsets 0,4,8,16,20,24. */
+int  mod_cluster_cloud_host(ModContext *ctx, const void *cloud, int32_t width, int32_t height,
+                            int32_t point_step, int32_t row_step,
+                            int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects);
+
+/* ---- device memory helpers (so a non-HIP host language can own HBM buffers) ------------------------------- */
+int  mod_malloc(ModContext *ctx, uint64_t bytes, void **dev_ptr);
+int  mod_free(ModContext *ctx, void *dev_ptr);
+int  mod_memcpy_h2d(ModContext *ctx, void *dev_dst, const void *host_src, uint64_t bytes);
+int  mod_memcpy_d2h(ModContext *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
+
+/* ---- measurement ------------------------------------------------------------------------------------------ */
+/* Stage timers: when enabled, each stage of the next calls is bracketed by HIP events on the context's stream. */
+#define MOD_STAGE_SCENE_FLOW  0   /* fused scene-flow kernel */
+#define MOD_STAGE_CCL         1   /* mask (if needed) + label propagation + flatten */
+#define MOD_STAGE_OBJECTS     2   /* stats + size filter/order + relabel + median velocity */
+#define MOD_STAGE_COUNT       3
+int  mod_set_profiling(ModContext *ctx, int32_t enable);
+/* Accumulated milliseconds and launch count of a stage since the last reset (synchronises the stream). */
+int  mod_get_stage_time(ModContext *ctx, int32_t stage, double *total_ms, int64_t *calls);
+int  mod_reset_stage_times(ModContext *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOD_SF_H_ */

@@ -1,0 +1,246 @@
+"""Deterministic synthetic stereo+flow inputs for the scene-flow / clustering hot path.
+
+The reference ships no data (no bags, no fixtures), so the workload is build-defined: a ground plane and a
+fronto-parallel wall seen by a ZED-like camera, K moving boxes large enough to survive ``cluster_size`` (Clusterer.cfg:8),
+two sub-threshold boxes, isolated dynamic pixels, and the invalid-value classes the reference code branches on
+(NaN / negative / zero / out-of-range disparity, NaN and huge flow).  What is produced is exactly the four values
+``SceneFlowConstructor::construct`` receives (scene_flow_constructor.cpp:91-97): disparity now, disparity previous,
+optical flow indexed at the *now* pixel with ``prev = now - flow`` (scene_flow_constructor.h:205-211) and the
+previous->now camera transform, plus ``dt``.
+
+Pure numpy, seeded per (config seed, frame index): identical bytes feed the CPU oracle and the HIP path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# (fx, fy, cx, cy, baseline) per resolution, SURVEY.md §8(d)
+_CAMERAS = {
+    (640, 480): (525.0, 525.0, 319.5, 239.5, 0.12),
+    (1280, 720): (700.0, 700.0, 640.0, 360.0, 0.12),
+    (1920, 1080): (1400.0, 1400.0, 960.0, 540.0, 0.12),
+}
+
+
+@dataclass
+class Camera:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    Tx: float = 0.0
+    Ty: float = 0.0
+    disp_f: float = 0.0
+    disp_T: float = 0.12
+    min_disparity: float = 0.0
+    max_disparity: float = 128.0
+
+
+@dataclass
+class Params:
+    """dynamic_reconfigure defaults: SceneFlowConstructor.cfg:8, Clusterer.cfg:8-11."""
+    dynamic_flow_diff: int = 5
+    cluster_size: int = 2500
+    neighbor_distance: int = 4
+    depth_diff: float = 0.15
+    dynamic_speed: float = 0.3
+
+
+@dataclass
+class Frame:
+    disparity_now: np.ndarray      # (H, W) float32
+    disparity_prev: np.ndarray     # (H, W) float32
+    flow: np.ndarray               # (H, W, 2) float32, x then y
+    translation: np.ndarray        # (3,) float64
+    quaternion: np.ndarray         # (4,) float64 x, y, z, w
+    dt: float
+    meta: dict = field(default_factory=dict)
+
+
+def make_camera(width: int, height: int) -> Camera:
+    if (width, height) in _CAMERAS:
+        fx, fy, cx, cy, base = _CAMERAS[(width, height)]
+    else:  # any other size: scale the 1280x720 ZED-like camera
+        s = width / 1280.0
+        fx = fy = 700.0 * s
+        cx, cy, base = (width - 1) / 2.0, (height - 1) / 2.0, 0.12
+    return Camera(width, height, fx, fy, cx, cy, 0.0, 0.0, np.float32(fx), np.float32(base), np.float32(0.0),
+                  np.float32(128.0))
+
+
+def _quat_from_yaw_pitch(yaw: float, pitch: float) -> np.ndarray:
+    """Camera frame: x right, y down, z forward.  Yaw about y, then pitch about x.  Returns x, y, z, w."""
+    cy_, sy_ = np.cos(yaw / 2), np.sin(yaw / 2)
+    cp_, sp_ = np.cos(pitch / 2), np.sin(pitch / 2)
+    qy = np.array([0.0, sy_, 0.0, cy_])
+    qx = np.array([sp_, 0.0, 0.0, cp_])
+
+    def mul(a, b):
+        ax, ay, az, aw = a
+        bx, by, bz, bw = b
+        return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+    return mul(qy, qx)
+
+
+def _rot(q: np.ndarray) -> np.ndarray:
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _background_depth(cam: Camera, origin: np.ndarray, R: np.ndarray, xs: np.ndarray, ys: np.ndarray,
+                      wall_z: float, cam_height: float) -> np.ndarray:
+    """Depth (camera z) of the wall/ground seen through pixel (xs, ys) of a camera at `origin` with axes `R`
+    (both expressed in the *now* frame, where wall: z = wall_z, ground: y = cam_height)."""
+    rx = (xs - cam.cx) / cam.fx
+    ry = (ys - cam.cy) / cam.fy
+    d = R @ np.stack([rx.ravel(), ry.ravel(), np.ones(rx.size)])
+    dx, dy, dz = (d[i].reshape(rx.shape) for i in range(3))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s_wall = (wall_z - origin[2]) / dz
+        s_ground = np.where(dy > 1e-9, (cam_height - origin[1]) / dy, np.inf)
+    s = np.minimum(np.where(s_wall > 0, s_wall, np.inf), np.where(s_ground > 0, s_ground, np.inf))
+    return np.clip(s, 2.0, 40.0)
+
+
+def make_frame(width: int = 1280, height: int = 720, seed: int = 0, frame: int = 0, *, n_objects: int = 6,
+               n_small: int = 2, n_isolated: int = 24, dt: float = 0.1, quantize: bool = True,
+               invalid: bool = True) -> tuple[Camera, Frame]:
+    """One stereo pair (now + previous disparity), its flow and ego-motion.
+
+    Object depth 4-9 m, speed 1-2 m/s and dt = 0.1 s (the KITTI-style value of SURVEY.md §8(d)) are chosen so that the
+    image-plane residual exceeds the reference's default ``dynamic_flow_diff`` of 5 px; slower / farther objects are
+    (faithfully) not detected by the reference at its defaults.
+    """
+    cam = make_camera(width, height)
+    W, H = width, height
+    rng = np.random.Generator(np.random.PCG64([0x5EED0000 + seed, frame]))
+    sc = W / 1280.0                                        # size scale relative to the 720p layout
+    f, base = float(cam.disp_f), float(cam.disp_T)
+
+    # ego-motion previous -> now: P_now = R P_prev + t (jittered around SURVEY's nominal values)
+    t = np.array([0.01, 0.0, 0.08]) * (1.0 + 0.2 * rng.uniform(-1, 1, 3))
+    yaw = np.deg2rad(0.4) * (1.0 + 0.2 * rng.uniform(-1, 1))
+    pitch = np.deg2rad(0.1) * (1.0 + 0.2 * rng.uniform(-1, 1))
+    q = _quat_from_yaw_pitch(yaw, pitch)
+    R = _rot(q)
+
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    wall_z, cam_h = 25.0 + 10.0 * rng.uniform(), 1.5
+
+    # --- now frame: background depth, then paint objects nearest-first-wins via a z-buffer -----------------------
+    z_now = _background_depth(cam, np.zeros(3), np.eye(3), xs, ys, wall_z, cam_h)
+    obj_id = np.full((H, W), -1, np.int32)
+    vel = np.zeros((H, W, 3))
+    # previous frame is seen from origin -R^T t with axes R^T (in now coordinates: centre = t... see below)
+    # P_now = R P_prev + t  =>  prev camera centre in now coords is t, prev axes are the columns of R.
+    z_prev = _background_depth(cam, t, R, xs, ys, wall_z, cam_h)
+    prev_obj = np.full((H, W), -1, np.int32)
+
+    boxes = []
+    for k in range(n_objects + n_small):
+        small = k >= n_objects
+        if small:
+            bw, bh = int(rng.integers(24, 44) * sc), int(rng.integers(24, 44) * sc)
+        else:
+            bw, bh = int(rng.integers(90, 261) * sc), int(rng.integers(120, 401) * sc)
+        bw, bh = max(bw, 3), max(bh, 3)
+        zc = rng.uniform(4.0, 9.0)
+        x0 = int(rng.integers(8, max(9, W - bw - 8)))
+        y0 = int(rng.integers(8, max(9, H - bh - 8)))
+        speed = rng.uniform(1.0, 2.0)
+        ang = rng.uniform(0, 2 * np.pi)
+        v = np.array([speed * np.cos(ang), 0.15 * speed * rng.uniform(-1, 1), 0.5 * speed * np.sin(ang)])
+        slant = rng.uniform(-0.3, 0.3) / max(bw, 1)        # depth gradient across the box [m/px]
+        boxes.append((x0, y0, bw, bh, zc, v, slant))
+    order = np.argsort([-b[4] for b in boxes])             # far to near, near overwrites
+    for k in order:
+        x0, y0, bw, bh, zc, v, slant = boxes[k]
+        sl = (slice(y0, y0 + bh), slice(x0, x0 + bw))
+        zz = zc + slant * (xs[sl] - (x0 + bw / 2.0))
+        closer = zz < z_now[sl]
+        z_now[sl] = np.where(closer, zz, z_now[sl])
+        obj_id[sl] = np.where(closer, k, obj_id[sl])
+        vel[sl] = np.where(closer[..., None], v, vel[sl])
+        # the same box one frame earlier, as seen by the previous camera (kept fronto-parallel)
+        c_now = np.array([(x0 + bw / 2.0 - cam.cx) / cam.fx * zc, (y0 + bh / 2.0 - cam.cy) / cam.fy * zc, zc])
+        c_prev = R.T @ (c_now - v * dt - t)
+        pw, ph = bw * zc / c_prev[2], bh * zc / c_prev[2]
+        px0 = int(round(cam.fx * c_prev[0] / c_prev[2] + cam.cx - pw / 2.0))
+        py0 = int(round(cam.fy * c_prev[1] / c_prev[2] + cam.cy - ph / 2.0))
+        xa, xb = max(px0, 0), min(px0 + int(round(pw)), W)
+        ya, yb = max(py0, 0), min(py0 + int(round(ph)), H)
+        if xa < xb and ya < yb:
+            psl = (slice(ya, yb), slice(xa, xb))
+            pz = c_prev[2] + slant * (xs[psl] - (px0 + pw / 2.0))
+            pcl = pz < z_prev[psl]
+            z_prev[psl] = np.where(pcl, pz, z_prev[psl])
+            prev_obj[psl] = np.where(pcl, k, prev_obj[psl])
+
+    # --- flow at the now pixel: where was this surface point one frame ago? ---------------------------------------
+    Pn = np.stack([(xs - cam.cx) / cam.fx * z_now, (ys - cam.cy) / cam.fy * z_now, z_now], -1)
+    Pp = (Pn - vel * dt - t) @ R                            # R^T (P - v dt - t), row-vector form
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xp = cam.fx * Pp[..., 0] / Pp[..., 2] + cam.cx
+        yp = cam.fy * Pp[..., 1] / Pp[..., 2] + cam.cy
+    flow = np.stack([xs - xp, ys - yp], -1)
+    flow += rng.uniform(-0.3, 0.3, flow.shape)
+
+    d_now = f * base / z_now
+    d_prev = f * base / z_prev
+    if quantize:                                            # quarter-pixel SGM-like quantisation
+        d_now = np.round(d_now * 4.0) / 4.0
+        d_prev = np.round(d_prev * 4.0) / 4.0
+    d_now = d_now.astype(np.float32)
+    d_prev = d_prev.astype(np.float32)
+    flow = flow.astype(np.float32)
+
+    # isolated dynamic pixels: a flow outlier of 10-30 px on a background pixel
+    n_iso = 0
+    for _ in range(n_isolated):
+        x, y = int(rng.integers(40, W - 40)), int(rng.integers(40, H - 40))
+        if obj_id[y, x] >= 0:
+            continue
+        a = rng.uniform(0, 2 * np.pi)
+        r = rng.uniform(10, 30)
+        flow[y, x, 0] += np.float32(r * np.cos(a))
+        flow[y, x, 1] += np.float32(r * np.sin(a))
+        n_iso += 1
+
+    if invalid:
+        for d in (d_now, d_prev):
+            u = rng.random((H, W))
+            d[u < 0.03] = np.nan
+            d[(u >= 0.03) & (u < 0.04)] = -1.0
+            d[(u >= 0.04) & (u < 0.05)] = 0.0
+            d[(u >= 0.05) & (u < 0.06)] = 200.0            # > max_disparity
+        u = rng.random((H, W))
+        flow[u < 0.01] = np.nan
+        huge = (u >= 0.01) & (u < 0.011)
+        flow[huge] = np.where(rng.random((int(huge.sum()), 2)) < 0.5, np.float32(-1e6), np.float32(1e6))
+
+    meta = {"n_boxes": n_objects, "n_small": n_small, "n_isolated": n_iso,
+            "object_pixels": int((obj_id >= 0).sum()), "wall_z": wall_z}
+    return cam, Frame(d_now, d_prev, flow, t.astype(np.float64), q.astype(np.float64), float(dt), meta)
+
+
+def make_batch(width: int, height: int, frames: int, seed: int = 0, first_frame: int = 0, **kw):
+    """`frames` independent pairs stacked: disparity_now/prev (F,H,W), flow (F,H,W,2), t (F,3), q (F,4), dt (F,)."""
+    cam = make_camera(width, height)
+    dn = np.empty((frames, height, width), np.float32)
+    dp = np.empty((frames, height, width), np.float32)
+    fl = np.empty((frames, height, width, 2), np.float32)
+    ts = np.empty((frames, 3), np.float64)
+    qs = np.empty((frames, 4), np.float64)
+    dts = np.empty((frames,), np.float64)
+    for i in range(frames):
+        _, fr = make_frame(width, height, seed, first_frame + i, **kw)
+        dn[i], dp[i], fl[i], ts[i], qs[i], dts[i] = fr.disparity_now, fr.disparity_prev, fr.flow, fr.translation, fr.quaternion, fr.dt
+    return cam, {"disparity_now": dn, "disparity_prev": dp, "flow": fl, "t": ts, "q": qs, "dt": dts}
