@@ -1,0 +1,69 @@
+// mod_device.h — device-side constants and small helpers shared by the gfx950 kernels.
+// Written for CDNA4 only: 64-lane wavefronts are assumed throughout (ballots are 64-bit, tiles are 64 px wide).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MOD_WAVE 64
+
+// Camera / parameter block as the kernels see it.  Everything that the reference computes per pixel but that only
+// depends on the camera (F32 product f*T, pixel rays, threshold conversions) is computed ONCE on the host with the same
+// IEEE operations and uploaded, so the per-pixel results stay bit-identical to the reference expressions.
+struct DevCam {
+  int32_t W, H;
+  int32_t mask_words;      // ceil(W/64)
+  int32_t n;               // neighbor_distance
+  int32_t cluster_size;
+  float fT;                // F32(f * T)                       disparity_image_processor.cpp:44
+  float dmin, dmax;        // min/max_disparity                disparity_image_processor.cpp:25-27
+  float flow_th;           // (float)dynamic_flow_diff         scene_flow_constructor.cpp:198
+  float speed_th;          // smallest F32 t with (double)t >= dynamic_speed   (clusterer_nodelet.cpp:51)
+  float depth_th;          // largest  F32 t with (double)t <= depth_diff      (clusterer_nodelet.cpp:194)
+  double speed_th_d;       // dynamic_speed itself (object acceptance test, clusterer_nodelet.cpp:176)
+  double fx, fy, cx, cy, Tx, Ty;  // project3dToPixel, scene_flow_constructor.cpp:84
+  const double *rayx;      // [W] (u - cx - Tx)/fx in F64       projectPixelTo3dRay, disparity_image_processor.cpp:45
+  const double *rayy;      // [H] (v - cy - Ty)/fy
+};
+
+// Per-frame constants: previous->now isometry (row-major 3x4: rotation | translation) and dt.
+struct FrameConst {
+  double m[12];
+  double dt;
+  double pad[3];
+};
+
+// Per-component record (32 bytes).  Filled by the stats kernel with wave-aggregated atomics.
+struct CompRec {
+  int32_t size;        // member count
+  int32_t key;         // first_edge_key (min raster index of a member with an up-left edge); later: new label or -1
+  uint32_t mn[3];      // ordered-uint encodings of min x,y,z
+  uint32_t mx[3];      // ordered-uint encodings of max x,y,z
+};
+
+// Per surviving cluster (after the size filter), in label order.
+struct ClusterInfo {
+  int32_t comp;        // component id (index into CompRec)
+  int32_t size;
+  int32_t offset;      // start of its member segment
+  int32_t med_pix;     // pixel index of the member chosen as the median-velocity element
+  uint32_t med_bits;   // F32 bits of that member's ||v||
+  int32_t ambiguous;   // 1 when members tie on ||v|| with different vectors (introsort-defined choice)
+  int32_t pad[2];
+};
+
+__device__ __forceinline__ uint32_t f2ord(float f) {   // monotone float -> uint
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+  uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(u);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Eigen Vector3f::norm(): sqrt(x^2 + (y^2 + z^2)), every step rounded to F32 (no contraction).
+__device__ __forceinline__ float norm3_f32(float vx, float vy, float vz) {
+  float xx = __fmul_rn(vx, vx), yy = __fmul_rn(vy, vy), zz = __fmul_rn(vz, vz);
+  return __fsqrt_rn(__fadd_rn(xx, __fadd_rn(yy, zz)));
+}

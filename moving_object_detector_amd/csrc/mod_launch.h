@@ -1,0 +1,45 @@
+// mod_launch.h — host-callable launchers of the gfx950 kernels (internal to libmod_sf.so).
+#pragma once
+#include "mod_device.h"
+
+struct SfArgs {
+  const float *dnow, *dprev, *flow;   // [F][H][W], [F][H][W], [F][H][W][2]
+  float *x, *y, *z, *vx, *vy, *vz;    // [F][H][W]
+  uint64_t *mask;                     // [F][H][mask_words] or null
+  float4 *aos;                        // [F][H][W][2 x float4] or null
+  float *depth;                       // [F][H][W] or null
+  float *sflow;                       // [F][H][W][2] or null
+  const FrameConst *fc;               // [F] device
+};
+
+// Scratch the clustering kernels work in; all device pointers, sized by the context.
+struct ClArgs {
+  const float *x, *y, *z, *vx, *vy, *vz;  // input planes [F][H][W]
+  const uint64_t *mask;       // [F][H][mask_words] dynamic bits
+  uint64_t *edge_up;          // [F][H][mask_words] pixel has >=1 up-left edge (first_edge_key candidates)
+  uint64_t *edge_any;         // [F][H][mask_words] pixel has any edge (member of a labelled component)
+  int32_t *parent;            // [F][N] union-find parents (only dynamic entries are ever touched)
+  int32_t *labels;            // [F][N] output plane; used as the root/code plane in between
+  CompRec *comps;             // [F][comp_cap]
+  int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects, 3 overflow flags
+  ClusterInfo *clusters;      // [F][max_objects]
+  uint2 *members;             // [F][N] (norm bits, pixel index), grouped per cluster
+  int32_t *cursors;           // [F][max_objects] fill cursors of the member segments
+  void *objects;              // [F][max_objects] ModObject
+  int32_t *n_objects;         // [F]
+  int32_t *n_clusters;        // [F] or null
+  int32_t comp_cap;
+  int32_t max_objects;
+};
+
+void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s);
+void launch_dynamic_mask(const DevCam &c, int frames, const float *vx, const float *vy, const float *vz, uint64_t *mask,
+                         hipStream_t s);
+void launch_pack(size_t n, const float *x, const float *y, const float *z, const float *vx, const float *vy, const float *vz,
+                 void *aos, hipStream_t s);
+void launch_unpack(size_t n, const void *aos, float *x, float *y, float *z, float *vx, float *vy, float *vz, hipStream_t s);
+
+// label propagation: parent init + windowed union + flatten (MOD_STAGE_CCL)
+void launch_ccl(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+// stats + size filter/order + relabel/member compaction + median velocity + object emission (MOD_STAGE_OBJECTS)
+void launch_objects(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);

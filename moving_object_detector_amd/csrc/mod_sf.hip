@@ -1,0 +1,528 @@
+// mod_sf.hip — C ABI (include/mod_sf.h) over the gfx950 kernels: context, scratch, parameter folding, stage timers.
+// Host-side only; the kernels live in sceneflow.hip and cluster.hip.
+#include "../../include/mod_sf.h"
+#include "mod_launch.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int kRing = 4;   // pinned staging slots for the per-frame constants
+
+struct EventPair { hipEvent_t a, b; };
+
+struct Buffers {
+  double *rayx = nullptr, *rayy = nullptr;
+  FrameConst *fc = nullptr;                 // [maxF]
+  uint64_t *mask = nullptr, *edge_up = nullptr, *edge_any = nullptr;
+  int32_t *parent = nullptr;
+  CompRec *comps = nullptr;
+  int32_t *counters = nullptr;
+  ClusterInfo *clusters = nullptr;          // 2 x [maxF][max_objects]
+  uint2 *members = nullptr;
+  int32_t *cursors = nullptr;
+  // one-frame staging for the *_host entry points (allocated on first use)
+  float *h_dnow = nullptr, *h_dprev = nullptr, *h_flow = nullptr, *h_planes = nullptr;
+  void *h_aos = nullptr;
+  int32_t *h_labels = nullptr, *h_nobj = nullptr;
+  ModObject *h_objects = nullptr;
+};
+
+}  // namespace
+
+struct ModContext {
+  ModConfig cfg{};
+  ModCamera cam{};
+  ModParams prm{};
+  bool has_cam = false, has_prm = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  DevCam dc{};
+  Buffers b;
+  int comp_cap = 0;
+  int max_objects = 0;
+  size_t maxN = 0;
+  int max_mask_words = 0;
+  FrameConst *pinned[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t pinned_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
+  int ring_pos = 0;
+  bool profiling = false;
+  std::vector<EventPair> pending[MOD_STAGE_COUNT];
+  std::vector<EventPair> free_events;
+  double stage_ms[MOD_STAGE_COUNT] = {0, 0, 0};
+  int64_t stage_calls[MOD_STAGE_COUNT] = {0, 0, 0};
+  std::string err;
+};
+
+namespace {
+
+int fail(ModContext *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(ctx, MOD_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+// smallest float t with (double)t >= th: for float a, ((double)a >= th) <=> (a >= t)
+float ceil_to_f32(double th) {
+  if (std::isnan(th)) return std::nanf("");
+  float t = (float)th;
+  if ((double)t < th) t = std::nextafterf(t, INFINITY);
+  return t;
+}
+// largest float t with (double)t <= th: for float a, ((double)a > th) <=> (a > t)
+float floor_to_f32(double th) {
+  if (std::isnan(th)) return std::nanf("");
+  float t = (float)th;
+  if ((double)t > th) t = std::nextafterf(t, -INFINITY);
+  return t;
+}
+
+// Eigen::Quaterniond::toRotationMatrix operation order (tf2::transformToEigen, scene_flow_constructor.cpp:411);
+// the quaternion is used as given, without normalisation.
+void transform_to_rows(const ModTransform &tf, double m[12]) {
+  const double x = tf.q[0], y = tf.q[1], z = tf.q[2], w = tf.q[3];
+  const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  m[0] = 1.0 - (tyy + tzz); m[1] = txy - twz;         m[2] = txz + twy;          m[3] = tf.t[0];
+  m[4] = txy + twz;         m[5] = 1.0 - (txx + tzz); m[6] = tyz - twx;          m[7] = tf.t[1];
+  m[8] = txz - twy;         m[9] = tyz + twx;         m[10] = 1.0 - (txx + tyy); m[11] = tf.t[2];
+}
+
+void refresh_devcam(ModContext *c) {
+  DevCam &d = c->dc;
+  d.W = c->cam.width; d.H = c->cam.height;
+  d.mask_words = mod_mask_words(d.W);
+  d.n = c->prm.neighbor_distance;
+  d.cluster_size = c->prm.cluster_size;
+  d.fT = c->cam.disp_f * c->cam.disp_T;               // F32 product, exactly the reference's `focal_length * baseline`
+  d.dmin = c->cam.min_disparity; d.dmax = c->cam.max_disparity;
+  d.flow_th = (float)c->prm.dynamic_flow_diff;
+  d.speed_th = ceil_to_f32(c->prm.dynamic_speed);
+  d.depth_th = floor_to_f32(c->prm.depth_diff);
+  d.speed_th_d = c->prm.dynamic_speed;
+  d.fx = c->cam.fx; d.fy = c->cam.fy; d.cx = c->cam.cx; d.cy = c->cam.cy; d.Tx = c->cam.Tx; d.Ty = c->cam.Ty;
+  d.rayx = c->b.rayx; d.rayy = c->b.rayy;
+}
+
+int check_ready(ModContext *c, int frames) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  if (!c->has_cam || !c->has_prm) return fail(c, MOD_ERR_NOT_CONFIGURED, "camera and parameters must be set first");
+  if (frames < 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "frames must be >= 1");
+  if (frames > c->cfg.max_frames) return fail(c, MOD_ERR_CAPACITY, "frames exceeds ModConfig.max_frames");
+  return MOD_OK;
+}
+
+struct StageTimer {
+  ModContext *c; int stage; EventPair ev{}; bool on;
+  StageTimer(ModContext *ctx, int st) : c(ctx), stage(st), on(ctx->profiling) {
+    if (!on) return;
+    if (!c->free_events.empty()) { ev = c->free_events.back(); c->free_events.pop_back(); }
+    else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+    (void)hipEventRecord(ev.a, c->stream);
+  }
+  ~StageTimer() {
+    if (!on) return;
+    (void)hipEventRecord(ev.b, c->stream);
+    c->pending[stage].push_back(ev);
+  }
+};
+
+void drain_timers(ModContext *c) {
+  for (int s = 0; s < MOD_STAGE_COUNT; s++) {
+    for (EventPair &ev : c->pending[s]) {
+      (void)hipEventSynchronize(ev.b);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { c->stage_ms[s] += ms; c->stage_calls[s] += 1; }
+      c->free_events.push_back(ev);
+    }
+    c->pending[s].clear();
+  }
+}
+
+int upload_frame_consts(ModContext *c, const ModFrameBatch *in) {
+  const int slot = c->ring_pos;
+  c->ring_pos = (c->ring_pos + 1) % kRing;
+  HIP_TRY(c, hipEventSynchronize(c->pinned_ev[slot]));   // the slot's previous copy has left the host buffer
+  FrameConst *h = c->pinned[slot];
+  for (int f = 0; f < in->frames; f++) {
+    transform_to_rows(in->transforms[f], h[f].m);
+    h[f].dt = in->dt[f];
+    h[f].pad[0] = h[f].pad[1] = h[f].pad[2] = 0.0;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->b.fc, h, sizeof(FrameConst) * in->frames, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->pinned_ev[slot], c->stream));
+  return MOD_OK;
+}
+
+int check_batch(ModContext *c, const ModFrameBatch *in) {
+  if (!in) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null batch");
+  int rc = check_ready(c, in->frames);
+  if (rc) return rc;
+  // construct()'s guards: nothing is published when an input is missing (scene_flow_constructor.cpp:104,110,122,127,133)
+  if (!in->flow) return MOD_SKIP_NO_FLOW;
+  if (!in->disparity_prev) return MOD_SKIP_NO_DISPARITY_PREV;
+  if (!in->transforms || !in->dt) return MOD_SKIP_NO_TRANSFORM;
+  if (!in->disparity_now) return MOD_SKIP_NO_DISPARITY_NOW;
+  return MOD_OK;
+}
+
+int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask) {
+  if (!out || !out->x || !out->y || !out->z || !out->vx || !out->vy || !out->vz)
+    return fail(c, MOD_ERR_INVALID_ARGUMENT, "scene-flow output planes x,y,z,vx,vy,vz are required");
+  int rc = upload_frame_consts(c, in);
+  if (rc) return rc;
+  SfArgs a;
+  a.dnow = in->disparity_now; a.dprev = in->disparity_prev; a.flow = in->flow;
+  a.x = out->x; a.y = out->y; a.z = out->z; a.vx = out->vx; a.vy = out->vy; a.vz = out->vz;
+  a.mask = mask; a.aos = (float4 *)out->cloud_aos; a.depth = out->depth; a.sflow = out->static_flow;
+  a.fc = c->b.fc;
+  {
+    StageTimer t(c, MOD_STAGE_SCENE_FLOW);
+    launch_scene_flow(c->dc, a, in->frames, c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready,
+                const ModClusterOut *out) {
+  if (!pl || !pl->x || !pl->y || !pl->z || !pl->vx || !pl->vy || !pl->vz)
+    return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster input planes x,y,z,vx,vy,vz are required");
+  if (!out || !out->labels || !out->objects || !out->n_objects)
+    return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster outputs labels, objects, n_objects are required");
+  ClArgs a;
+  a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
+  a.mask = mask; a.edge_up = c->b.edge_up; a.edge_any = c->b.edge_any; a.parent = c->b.parent;
+  a.labels = out->labels; a.comps = c->b.comps; a.counters = c->b.counters; a.clusters = c->b.clusters;
+  a.members = c->b.members; a.cursors = c->b.cursors; a.objects = out->objects; a.n_objects = out->n_objects;
+  a.n_clusters = out->n_clusters; a.comp_cap = c->comp_cap; a.max_objects = c->max_objects;
+  {
+    StageTimer t(c, MOD_STAGE_CCL);
+    if (!mask_ready) launch_dynamic_mask(c->dc, frames, pl->vx, pl->vy, pl->vz, (uint64_t *)mask, c->stream);
+    HIP_TRY(c, hipMemsetAsync(c->b.counters, 0, sizeof(int32_t) * 8 * frames, c->stream));
+    launch_ccl(c->dc, a, frames, c->stream);
+  }
+  {
+    StageTimer t(c, MOD_STAGE_OBJECTS);
+    launch_objects(c->dc, a, frames, c->stream);
+  }
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+template <class T>
+hipError_t dalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
+
+}  // namespace
+
+extern "C" {
+
+int mod_abi_version(void) { return MOD_ABI_VERSION; }
+
+int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
+  if (!cfg || !out_ctx) return MOD_ERR_INVALID_ARGUMENT;
+  *out_ctx = nullptr;
+  if (cfg->max_width < 1 || cfg->max_height < 1 || cfg->max_frames < 1) return MOD_ERR_INVALID_ARGUMENT;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= cfg->device || cfg->device < 0) return MOD_ERR_NO_DEVICE;
+  if (hipSetDevice(cfg->device) != hipSuccess) return MOD_ERR_NO_DEVICE;
+  ModContext *c = new ModContext();
+  c->cfg = *cfg;
+  const size_t N = (size_t)cfg->max_width * cfg->max_height;
+  const int F = cfg->max_frames;
+  c->maxN = N;
+  c->max_mask_words = mod_mask_words(cfg->max_width);
+  c->max_objects = cfg->max_objects > 0 ? cfg->max_objects : (int)std::max<size_t>(1, N / 100);
+  c->comp_cap = (int)(N / 2 + 1);
+  if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+  else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MOD_ERR_DEVICE; } c->own_stream = true; }
+  const size_t mw = (size_t)F * cfg->max_height * c->max_mask_words;
+  bool ok = true;
+  ok &= dalloc(&c->b.rayx, cfg->max_width + 4) == hipSuccess;
+  ok &= dalloc(&c->b.rayy, cfg->max_height + 4) == hipSuccess;
+  ok &= dalloc(&c->b.fc, F) == hipSuccess;
+  ok &= dalloc(&c->b.mask, mw) == hipSuccess;
+  ok &= dalloc(&c->b.edge_up, mw) == hipSuccess;
+  ok &= dalloc(&c->b.edge_any, mw) == hipSuccess;
+  ok &= dalloc(&c->b.parent, (size_t)F * N) == hipSuccess;
+  ok &= dalloc(&c->b.comps, (size_t)F * c->comp_cap) == hipSuccess;
+  ok &= dalloc(&c->b.counters, (size_t)F * 8) == hipSuccess;
+  ok &= dalloc(&c->b.clusters, (size_t)2 * F * c->max_objects) == hipSuccess;
+  ok &= dalloc(&c->b.members, (size_t)F * N) == hipSuccess;
+  ok &= dalloc(&c->b.cursors, (size_t)F * c->max_objects) == hipSuccess;
+  for (int i = 0; i < kRing && ok; i++) {
+    ok &= hipHostMalloc((void **)&c->pinned[i], sizeof(FrameConst) * F, hipHostMallocDefault) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&c->pinned_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (ok) ok &= hipEventRecord(c->pinned_ev[i], c->stream) == hipSuccess;
+  }
+  if (!ok) { mod_destroy(c); return MOD_ERR_DEVICE; }
+  *out_ctx = c;
+  return MOD_OK;
+}
+
+void mod_destroy(ModContext *c) {
+  if (!c) return;
+  (void)hipStreamSynchronize(c->stream);
+  Buffers &b = c->b;
+  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.edge_up, b.edge_any, b.parent, b.comps, b.counters, b.clusters, b.members,
+                 b.cursors, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
+  for (void *p : dev) if (p) (void)hipFree(p);
+  for (int i = 0; i < kRing; i++) {
+    if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+    if (c->pinned_ev[i]) (void)hipEventDestroy(c->pinned_ev[i]);
+  }
+  for (int s = 0; s < MOD_STAGE_COUNT; s++) for (EventPair &e : c->pending[s]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (EventPair &e : c->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *mod_last_error(const ModContext *c) { return c ? c->err.c_str() : "null context"; }
+
+int mod_set_camera(ModContext *c, const ModCamera *cam) {
+  if (!c || !cam) return MOD_ERR_INVALID_ARGUMENT;
+  if (cam->width < 1 || cam->height < 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "camera size must be positive");
+  if (cam->width > c->cfg.max_width || cam->height > c->cfg.max_height || (size_t)cam->width * cam->height > c->maxN)
+    return fail(c, MOD_ERR_CAPACITY, "camera larger than ModConfig.max_width/max_height");
+  c->cam = *cam;
+  // projectPixelTo3dRay (image_geometry, melodic): ((u - cx - Tx)/fx, (v - cy - Ty)/fy, 1) in F64 — only a function of
+  // the column / the row, so the two F64 divides per pixel of the reference become two table reads.
+  std::vector<double> rx(cam->width + 4, 0.0), ry(cam->height + 4, 0.0);
+  for (int u = 0; u < cam->width; u++) rx[u] = ((double)u - cam->cx - cam->Tx) / cam->fx;
+  for (int v = 0; v < cam->height; v++) ry[v] = ((double)v - cam->cy - cam->Ty) / cam->fy;
+  HIP_TRY(c, hipMemcpyAsync(c->b.rayx, rx.data(), sizeof(double) * rx.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->b.rayy, ry.data(), sizeof(double) * ry.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // rx/ry are stack-owned
+  c->has_cam = true;
+  refresh_devcam(c);
+  return MOD_OK;
+}
+
+int mod_set_params(ModContext *c, const ModParams *p) {
+  if (!c || !p) return MOD_ERR_INVALID_ARGUMENT;
+  if (p->neighbor_distance < 1 || p->neighbor_distance > MOD_MAX_NEIGHBOR_DISTANCE)
+    return fail(c, MOD_ERR_INVALID_ARGUMENT, "neighbor_distance must be in 1..16");
+  if (p->cluster_size < 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster_size must be >= 1");
+  c->prm = *p;
+  c->has_prm = true;
+  refresh_devcam(c);
+  return MOD_OK;
+}
+
+int mod_get_camera(const ModContext *c, ModCamera *cam) {
+  if (!c || !cam || !c->has_cam) return MOD_ERR_NOT_CONFIGURED;
+  *cam = c->cam;
+  return MOD_OK;
+}
+int mod_get_params(const ModContext *c, ModParams *p) {
+  if (!c || !p || !c->has_prm) return MOD_ERR_NOT_CONFIGURED;
+  *p = c->prm;
+  return MOD_OK;
+}
+
+int mod_synchronize(ModContext *c) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MOD_OK;
+}
+
+int mod_scene_flow_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out) {
+  int rc = check_batch(c, in);
+  if (rc) return rc;
+  return run_scene_flow(c, in, out, out ? out->dynamic_mask : nullptr);
+}
+
+int mod_dynamic_mask_dev(ModContext *c, int32_t frames, const float *vx, const float *vy, const float *vz, uint64_t *mask) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  if (!vx || !vy || !vz || !mask) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null plane");
+  launch_dynamic_mask(c->dc, frames, vx, vy, vz, mask, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+int mod_cluster_dev(ModContext *c, int32_t frames, const ModSceneFlowPlanes *pl, const ModClusterOut *out) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  const bool have = pl && pl->dynamic_mask;
+  return run_cluster(c, frames, pl, have ? pl->dynamic_mask : c->b.mask, have, out);
+}
+
+int mod_process_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *pl, const ModClusterOut *out) {
+  int rc = check_batch(c, in);
+  if (rc) return rc;
+  uint64_t *mask = (pl && pl->dynamic_mask) ? pl->dynamic_mask : c->b.mask;
+  rc = run_scene_flow(c, in, pl, mask);
+  if (rc) return rc;
+  return run_cluster(c, in->frames, pl, mask, true, out);
+}
+
+int mod_pack_cloud_dev(ModContext *c, int32_t frames, const ModSceneFlowPlanes *pl, void *aos) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  if (!pl || !aos || !pl->x || !pl->y || !pl->z || !pl->vx || !pl->vy || !pl->vz) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null plane");
+  launch_pack((size_t)frames * c->dc.W * c->dc.H, pl->x, pl->y, pl->z, pl->vx, pl->vy, pl->vz, aos, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+int mod_unpack_cloud_dev(ModContext *c, int32_t frames, const void *aos, const ModSceneFlowPlanes *pl) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  if (!pl || !aos || !pl->x || !pl->y || !pl->z || !pl->vx || !pl->vy || !pl->vz) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null plane");
+  launch_unpack((size_t)frames * c->dc.W * c->dc.H, aos, pl->x, pl->y, pl->z, pl->vx, pl->vy, pl->vz, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+// ---- host-pointer convenience --------------------------------------------------------------------------------------
+static int ensure_host_staging(ModContext *c) {
+  Buffers &b = c->b;
+  if (b.h_dnow) return MOD_OK;
+  const size_t N = c->maxN;
+  HIP_TRY(c, dalloc(&b.h_dnow, N));
+  HIP_TRY(c, dalloc(&b.h_dprev, N));
+  HIP_TRY(c, dalloc(&b.h_flow, 2 * N));
+  HIP_TRY(c, dalloc(&b.h_planes, 6 * N));
+  HIP_TRY(c, hipMalloc(&b.h_aos, 32 * N));
+  HIP_TRY(c, dalloc(&b.h_labels, N));
+  HIP_TRY(c, dalloc(&b.h_nobj, 8));
+  HIP_TRY(c, dalloc(&b.h_objects, (size_t)c->max_objects));
+  return MOD_OK;
+}
+
+static void staged_planes(ModContext *c, ModSceneFlowPlanes *pl) {
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  float *p = c->b.h_planes;
+  memset(pl, 0, sizeof(*pl));
+  pl->x = p; pl->y = p + N; pl->z = p + 2 * N; pl->vx = p + 3 * N; pl->vy = p + 4 * N; pl->vz = p + 5 * N;
+}
+
+static int fetch_cluster_results(ModContext *c, int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects) {
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  int32_t n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, c->b.h_nobj, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (labels) HIP_TRY(c, hipMemcpyAsync(labels, c->b.h_labels, sizeof(int32_t) * N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (n_objects) *n_objects = n;
+  const int32_t ncopy = std::min(n, std::min(max_objects, (int32_t)c->max_objects));
+  if (objects && ncopy > 0) {
+    HIP_TRY(c, hipMemcpyAsync(objects, c->b.h_objects, sizeof(ModObject) * ncopy, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  }
+  return MOD_OK;
+}
+
+int mod_process_frame_host(ModContext *c, const float *disparity_now, const float *disparity_prev, const float *flow,
+                           const ModTransform *transform, double dt, void *cloud_aos, int32_t *labels, ModObject *objects,
+                           int32_t max_objects, int32_t *n_objects) {
+  int rc = check_ready(c, 1);
+  if (rc) return rc;
+  if (n_objects) *n_objects = 0;
+  if (!flow) return MOD_SKIP_NO_FLOW;
+  if (!disparity_prev) return MOD_SKIP_NO_DISPARITY_PREV;
+  if (!transform) return MOD_SKIP_NO_TRANSFORM;
+  if (!disparity_now) return MOD_SKIP_NO_DISPARITY_NOW;
+  rc = ensure_host_staging(c);
+  if (rc) return rc;
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  Buffers &b = c->b;
+  HIP_TRY(c, hipMemcpyAsync(b.h_dnow, disparity_now, 4 * N, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b.h_dprev, disparity_prev, 4 * N, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(b.h_flow, flow, 8 * N, hipMemcpyHostToDevice, c->stream));
+  ModFrameBatch in{};
+  in.frames = 1; in.disparity_now = b.h_dnow; in.disparity_prev = b.h_dprev; in.flow = b.h_flow;
+  in.transforms = transform; in.dt = &dt;
+  ModSceneFlowPlanes pl;
+  staged_planes(c, &pl);
+  pl.cloud_aos = cloud_aos ? b.h_aos : nullptr;
+  ModClusterOut out{};
+  out.labels = b.h_labels; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
+  rc = mod_process_dev(c, &in, &pl, &out);
+  if (rc) return rc;
+  if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, b.h_aos, 32 * N, hipMemcpyDeviceToHost, c->stream));
+  return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
+}
+
+int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int32_t height, int32_t point_step,
+                           int32_t row_step, int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects) {
+  int rc = check_ready(c, 1);
+  if (rc) return rc;
+  if (n_objects) *n_objects = 0;
+  if (!cloud) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null cloud");
+  // an unorganized / mis-sized cloud is an error (the reference would throw from .at(), clusterer_nodelet.h:99-102)
+  if (width != c->dc.W || height != c->dc.H) return fail(c, MOD_ERR_INVALID_ARGUMENT, "cloud size differs from the configured camera");
+  if (point_step != 32 || row_step < 32 * width) return fail(c, MOD_ERR_INVALID_ARGUMENT, "expected PointXYZVelocity records (point_step 32)");
+  rc = ensure_host_staging(c);
+  if (rc) return rc;
+  Buffers &b = c->b;
+  HIP_TRY(c, hipMemcpy2DAsync(b.h_aos, (size_t)32 * width, cloud, (size_t)row_step, (size_t)32 * width, (size_t)height,
+                              hipMemcpyHostToDevice, c->stream));
+  ModSceneFlowPlanes pl;
+  staged_planes(c, &pl);
+  rc = mod_unpack_cloud_dev(c, 1, b.h_aos, &pl);
+  if (rc) return rc;
+  ModClusterOut out{};
+  out.labels = b.h_labels; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
+  rc = mod_cluster_dev(c, 1, &pl, &out);
+  if (rc) return rc;
+  return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
+}
+
+// ---- memory helpers --------------------------------------------------------------------------------------------------
+int mod_malloc(ModContext *c, uint64_t bytes, void **p) {
+  if (!c || !p) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipMalloc(p, bytes));
+  return MOD_OK;
+}
+int mod_free(ModContext *c, void *p) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipFree(p));
+  return MOD_OK;
+}
+int mod_memcpy_h2d(ModContext *c, void *d, const void *h, uint64_t bytes) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MOD_OK;
+}
+int mod_memcpy_d2h(ModContext *c, void *h, const void *d, uint64_t bytes) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MOD_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------------------------
+int mod_set_profiling(ModContext *c, int32_t enable) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  c->profiling = enable != 0;
+  return MOD_OK;
+}
+int mod_get_stage_time(ModContext *c, int32_t stage, double *total_ms, int64_t *calls) {
+  if (!c || stage < 0 || stage >= MOD_STAGE_COUNT) return MOD_ERR_INVALID_ARGUMENT;
+  drain_timers(c);
+  if (total_ms) *total_ms = c->stage_ms[stage];
+  if (calls) *calls = c->stage_calls[stage];
+  return MOD_OK;
+}
+int mod_reset_stage_times(ModContext *c) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  drain_timers(c);
+  for (int s = 0; s < MOD_STAGE_COUNT; s++) { c->stage_ms[s] = 0; c->stage_calls[s] = 0; }
+  return MOD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,263 @@
+// sceneflow.hip — fused scene-flow construction kernel for gfx950 (MI355X).
+//
+// One kernel replaces the five full-image CPU passes of SceneFlowConstructor::construct
+// (scene_flow_constructor/src/scene_flow_constructor.cpp:91-147):
+//   toPointCloud(now), toPointCloud(prev)   disparity_image_proc/src/disparity_image_processor.cpp:86-103,33-50
+//   transformPCPreviousToNow                scene_flow_constructor.cpp:409-429
+//   calculateStaticOpticalFlow              scene_flow_constructor.cpp:65-89
+//   constructVelocityPC (+ helpers)         scene_flow_constructor.cpp:149-212, scene_flow_constructor.h:173-249
+// and, as an epilogue, calculateDynamicMap  scene_flow_clusterer/src/clusterer_nodelet.cpp:40-54.
+//
+// Memory plan (HBM-bound): per pixel 16 B are read once (disp_now 4, disp_prev 4, flow 8) with
+// 16-byte-per-lane row-contiguous loads, 24 B are written as six SoA planes with 16-byte stores, plus 1 bit of mask.
+// The previous cloud is never materialised: the point at the flow-warped pixel is re-derived from one 4-byte gather
+// of disp_prev (served by L2 — the warp target is a few rows away) and two F64 ray-table entries.
+// Arithmetic follows the reference expression by expression (F32 vs F64 as annotated); FP contraction is off so
+// that every product and sum rounds exactly like the SSE2 build of the reference.
+#include "mod_launch.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct Px {          // result of one pixel
+  float x, y, z, vx, vy, vz, s0, s1, depth;
+  bool dyn;
+};
+
+__device__ __forceinline__ bool disp_in_range(const DevCam &c, float d) {
+  // getDisparity range gate (disparity_image_processor.cpp:25-28): a NaN passes both tests.
+  return !(c.dmax < d) && !(c.dmin > d);
+}
+
+// Rigid transform, Eigen association t + (p0 + (p1 + p2)) per row (see oracle/oracle.cpp iso_apply), result cast to F32.
+__device__ __forceinline__ void iso_apply(const FrameConst &fc, float X, float Y, float Z, float &ox, float &oy, float &oz) {
+  const double x = (double)X, y = (double)Y, z = (double)Z;
+  ox = (float)(fc.m[3] + (fc.m[0] * x + (fc.m[1] * y + fc.m[2] * z)));
+  oy = (float)(fc.m[7] + (fc.m[4] * x + (fc.m[5] * y + fc.m[6] * z)));
+  oz = (float)(fc.m[11] + (fc.m[8] * x + (fc.m[9] * y + fc.m[10] * z)));
+}
+
+// One pixel of constructVelocityPC with everything it depends on.
+//   dn  : disparity_now(x, y)      dpo : disparity_prev(x, y)      f0,f1 : flow(x, y)
+//   rx,ry : F64 pixel ray of (x, y)
+__device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, const float *__restrict__ dprev, int x, int y,
+                                         float dn, float dpo, float f0, float f1, double rx, double ry, Px &o) {
+  const float nan = __uint_as_float(0x7fc00000u);
+  o.x = o.y = o.z = o.vx = o.vy = o.vz = nan;
+  o.s0 = o.s1 = nan;
+  o.depth = nan;
+  o.dyn = false;
+
+  // ---- static flow at the own pixel: reproject prev, transform, project (always needed by the residual test) ----
+  {
+    const bool ok = disp_in_range(c, dpo) && !(dpo == 0.0f);
+    const float z = c.fT / dpo;                             // F32
+    const float X = (float)(rx * (double)z);                // F64 product -> F32
+    const float Y = (float)(ry * (double)z);
+    if (ok && !isnan(X)) {
+      float tx, ty, tz;
+      iso_apply(fc, X, Y, z, tx, ty, tz);
+      if (!isnan(tx)) {
+        const double u = (c.fx * (double)tx + c.Tx) / (double)tz + c.cx;     // project3dToPixel, F64
+        const double v = (c.fy * (double)ty + c.Ty) / (double)tz + c.cy;
+        o.s0 = (float)(u - (double)x);
+        o.s1 = (float)(v - (double)y);
+      }
+    }
+  }
+
+  // ---- now point ----
+  const bool okn = disp_in_range(c, dn) && !(dn == 0.0f);
+  const float zn = c.fT / dn;
+  const float Xn = (float)(rx * (double)zn);
+  const float Yn = (float)(ry * (double)zn);
+  if (okn) o.depth = zn;                                    // toDepthImage (disparity_image_processor.cpp:105-120)
+  if (!(okn && !isnan(Xn) && !isinf(Xn))) return;           // isValid tests x only (scene_flow_constructor.h:240-249)
+  o.x = Xn; o.y = Yn; o.z = zn;
+
+  // ---- getMatchPoints (scene_flow_constructor.h:173-227) ----
+  if (isnan(f0) || isnan(f1)) return;
+  const float rxf = roundf((float)x - f0);                  // std::round, F32, half away from zero
+  const float ryf = roundf((float)y - f1);
+  if (isnan(dn) || isinf(dn) || dn < 0.0f) return;          // getRightPoint(now)
+  // out-of-int-range warps are UB in the reference (x86 yields INT_MIN -> rejected by the bounds test): reject.
+  if (!(rxf >= 0.0f && rxf < (float)c.W && ryf >= 0.0f && ryf < (float)c.H)) return;
+  const int px = (int)rxf, py = (int)ryf;
+  const float dpw = dprev[(size_t)py * c.W + px];           // the one data-dependent gather
+  if (!disp_in_range(c, dpw)) return;                       // getRightPoint(previous): getDisparity ...
+  if (isnan(dpw) || isinf(dpw) || dpw < 0.0f) return;       // ... then NaN / inf / negative
+  if (dpw == 0.0f) return;                                  // prev cloud holds NaN there -> !isValid
+  const float zp = c.fT / dpw;
+  const float Xp = (float)(c.rayx[px] * (double)zp);
+  const float Yp = (float)(c.rayy[py] * (double)zp);
+  if (isnan(Xp)) return;                                    // NaN passes through the transform untouched -> invalid
+  float tx, ty, tz;
+  iso_apply(fc, Xp, Yp, zp, tx, ty, tz);
+  if (isnan(tx) || isinf(tx)) return;
+  if (isnan(o.s0)) return;                                  // static flow NaN (scene_flow_constructor.cpp:193)
+
+  // ---- residual test and velocity (scene_flow_constructor.cpp:196-209) ----
+  const float r0 = f0 - o.s0, r1 = f1 - o.s1;
+  float acc = 0.0f;
+  acc = acc + r0 * r0;
+  acc = acc + r1 * r1;
+  if (sqrtf(acc) >= c.flow_th) {
+    o.vx = (float)((double)(Xn - tx) / fc.dt);
+    o.vy = (float)((double)(Yn - ty) / fc.dt);
+    o.vz = (float)((double)(zn - tz) / fc.dt);
+    // calculateDynamicMap: (double)||v|| >= dynamic_speed, folded into an equivalent F32 threshold on the host
+    o.dyn = norm3_f32(o.vx, o.vy, o.vz) >= c.speed_th;
+  } else {
+    o.vx = 0.0f; o.vy = 0.0f; o.vz = 0.0f;
+    o.dyn = 0.0f >= c.speed_th;
+  }
+}
+
+// OR-combine the 4-bit nibbles of 16 consecutive lanes into one 64-bit word (lane 16k -> word k of the wave).
+__device__ __forceinline__ uint64_t nibbles_to_word(uint32_t nib, int lane) {
+  uint32_t v = nib << (4 * (lane & 7));
+  v |= __shfl_xor(v, 1);
+  v |= __shfl_xor(v, 2);
+  v |= __shfl_xor(v, 4);
+  const uint32_t hi = __shfl_down(v, 8);
+  return (uint64_t)v | ((uint64_t)hi << 32);
+}
+
+// Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
+__global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
+  const int lane = threadIdx.x;                      // 0..63
+  const int x0 = (blockIdx.x * 64 + lane) * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  const bool inb = (x0 < c.W) && (y < c.H);
+  const size_t N = (size_t)c.W * c.H;
+  const size_t base = (size_t)f * N + (size_t)y * c.W + x0;
+  const FrameConst fc = a.fc[f];
+  uint32_t nib = 0;
+  if (inb) {
+    const float4 dn = *reinterpret_cast<const float4 *>(a.dnow + base);
+    const float4 dp = *reinterpret_cast<const float4 *>(a.dprev + base);
+    const float4 fa = *reinterpret_cast<const float4 *>(a.flow + 2 * base);
+    const float4 fb = *reinterpret_cast<const float4 *>(a.flow + 2 * base + 4);
+    const double ry = c.rayy[y];
+    const double2 rxa = *reinterpret_cast<const double2 *>(c.rayx + x0);
+    const double2 rxb = *reinterpret_cast<const double2 *>(c.rayx + x0 + 2);
+    const float *dprev_f = a.dprev + (size_t)f * N;
+    Px p0, p1, p2, p3;
+    sf_pixel(c, fc, dprev_f, x0 + 0, y, dn.x, dp.x, fa.x, fa.y, rxa.x, ry, p0);
+    sf_pixel(c, fc, dprev_f, x0 + 1, y, dn.y, dp.y, fa.z, fa.w, rxa.y, ry, p1);
+    sf_pixel(c, fc, dprev_f, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2);
+    sf_pixel(c, fc, dprev_f, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3);
+    *reinterpret_cast<float4 *>(a.x + base) = make_float4(p0.x, p1.x, p2.x, p3.x);
+    *reinterpret_cast<float4 *>(a.y + base) = make_float4(p0.y, p1.y, p2.y, p3.y);
+    *reinterpret_cast<float4 *>(a.z + base) = make_float4(p0.z, p1.z, p2.z, p3.z);
+    *reinterpret_cast<float4 *>(a.vx + base) = make_float4(p0.vx, p1.vx, p2.vx, p3.vx);
+    *reinterpret_cast<float4 *>(a.vy + base) = make_float4(p0.vy, p1.vy, p2.vy, p3.vy);
+    *reinterpret_cast<float4 *>(a.vz + base) = make_float4(p0.vz, p1.vz, p2.vz, p3.vz);
+    if (a.aos) {   // pcl::PointXYZVelocity records, 32 B each (pads written as 0)
+      float4 *q = a.aos + 2 * base;
+      q[0] = make_float4(p0.x, p0.y, p0.z, 0.f); q[1] = make_float4(p0.vx, p0.vy, p0.vz, 0.f);
+      q[2] = make_float4(p1.x, p1.y, p1.z, 0.f); q[3] = make_float4(p1.vx, p1.vy, p1.vz, 0.f);
+      q[4] = make_float4(p2.x, p2.y, p2.z, 0.f); q[5] = make_float4(p2.vx, p2.vy, p2.vz, 0.f);
+      q[6] = make_float4(p3.x, p3.y, p3.z, 0.f); q[7] = make_float4(p3.vx, p3.vy, p3.vz, 0.f);
+    }
+    if (a.depth) *reinterpret_cast<float4 *>(a.depth + base) = make_float4(p0.depth, p1.depth, p2.depth, p3.depth);
+    if (a.sflow) {
+      *reinterpret_cast<float4 *>(a.sflow + 2 * base) = make_float4(p0.s0, p0.s1, p1.s0, p1.s1);
+      *reinterpret_cast<float4 *>(a.sflow + 2 * base + 4) = make_float4(p2.s0, p2.s1, p3.s0, p3.s1);
+    }
+    nib = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u) | (p2.dyn ? 4u : 0u) | (p3.dyn ? 8u : 0u);
+  }
+  if (a.mask) {   // wave-uniform branch; all 64 lanes take part in the shuffles
+    const uint64_t w = nibbles_to_word(nib, lane);
+    const int word = (blockIdx.x * 64 + lane) / 16;          // (x0 / 64)
+    if ((lane & 15) == 0 && y < c.H && word < c.mask_words)
+      a.mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
+  }
+}
+
+// Scalar kernel for widths that are not a multiple of 4: thread = 1 pixel, wave = 64 px of one row.
+__global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) {
+  const int lane = threadIdx.x;
+  const int x = blockIdx.x * 64 + lane;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  const bool inb = (x < c.W) && (y < c.H);
+  const size_t N = (size_t)c.W * c.H;
+  const size_t i = (size_t)f * N + (size_t)y * c.W + x;
+  const FrameConst fc = a.fc[f];
+  bool dyn = false;
+  if (inb) {
+    Px p;
+    sf_pixel(c, fc, a.dprev + (size_t)f * N, x, y, a.dnow[i], a.dprev[i], a.flow[2 * i], a.flow[2 * i + 1], c.rayx[x], c.rayy[y], p);
+    a.x[i] = p.x; a.y[i] = p.y; a.z[i] = p.z; a.vx[i] = p.vx; a.vy[i] = p.vy; a.vz[i] = p.vz;
+    if (a.aos) { a.aos[2 * i] = make_float4(p.x, p.y, p.z, 0.f); a.aos[2 * i + 1] = make_float4(p.vx, p.vy, p.vz, 0.f); }
+    if (a.depth) a.depth[i] = p.depth;
+    if (a.sflow) { a.sflow[2 * i] = p.s0; a.sflow[2 * i + 1] = p.s1; }
+    dyn = p.dyn;
+  }
+  if (a.mask) {
+    const uint64_t w = __ballot(dyn);
+    if (lane == 0 && y < c.H && blockIdx.x < (unsigned)c.mask_words) a.mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x] = w;
+  }
+}
+
+// calculateDynamicMap alone (clusterer_nodelet.cpp:40-54) for clouds that did not come from the fused kernel.
+__global__ __launch_bounds__(256) void k_dynamic_mask(DevCam c, const float *__restrict__ vx, const float *__restrict__ vy,
+                                                      const float *__restrict__ vz, uint64_t *__restrict__ mask) {
+  const int lane = threadIdx.x;
+  const int x = blockIdx.x * 64 + lane;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  bool dyn = false;
+  if (x < c.W && y < c.H) {
+    const size_t i = ((size_t)f * c.H + y) * c.W + x;
+    dyn = norm3_f32(vx[i], vy[i], vz[i]) >= c.speed_th;
+  }
+  const uint64_t w = __ballot(dyn);
+  if (lane == 0 && y < c.H && blockIdx.x < (unsigned)c.mask_words) mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x] = w;
+}
+
+// SoA <-> 32-byte AoS (pcl::toROSMsg / fromROSMsg payloads, scene_flow_constructor.cpp:358-361, clusterer_nodelet.cpp:226).
+__global__ __launch_bounds__(256) void k_pack(size_t n, const float *x, const float *y, const float *z, const float *vx,
+                                              const float *vy, const float *vz, float4 *aos) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  aos[2 * i] = make_float4(x[i], y[i], z[i], 0.f);
+  aos[2 * i + 1] = make_float4(vx[i], vy[i], vz[i], 0.f);
+}
+__global__ __launch_bounds__(256) void k_unpack(size_t n, const float4 *aos, float *x, float *y, float *z, float *vx, float *vy,
+                                                float *vz) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = aos[2 * i], b = aos[2 * i + 1];
+  x[i] = a.x; y[i] = a.y; z[i] = a.z; vx[i] = b.x; vy[i] = b.y; vz[i] = b.z;
+}
+
+}  // namespace
+
+void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s) {
+  dim3 block(64, 4, 1);
+  if ((c.W & 3) == 0) {
+    dim3 grid((c.W / 4 + 63) / 64, (c.H + 3) / 4, frames);
+    hipLaunchKernelGGL(k_scene_flow_v4, grid, block, 0, s, c, a);
+  } else {
+    dim3 grid((c.W + 63) / 64, (c.H + 3) / 4, frames);
+    hipLaunchKernelGGL(k_scene_flow_v1, grid, block, 0, s, c, a);
+  }
+}
+
+void launch_dynamic_mask(const DevCam &c, int frames, const float *vx, const float *vy, const float *vz, uint64_t *mask,
+                         hipStream_t s) {
+  dim3 block(64, 4, 1), grid((c.W + 63) / 64, (c.H + 3) / 4, frames);
+  hipLaunchKernelGGL(k_dynamic_mask, grid, block, 0, s, c, vx, vy, vz, mask);
+}
+
+void launch_pack(size_t n, const float *x, const float *y, const float *z, const float *vx, const float *vy, const float *vz,
+                 void *aos, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, x, y, z, vx, vy, vz, (float4 *)aos);
+}
+void launch_unpack(size_t n, const void *aos, float *x, float *y, float *z, float *vx, float *vy, float *vz, hipStream_t s) {
+  hipLaunchKernelGGL(k_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, (const float4 *)aos, x, y, z, vx, vy, vz);
+}

@@ -205,7 +205,8 @@ def make_frame(width: int = 1280, height: int = 720, seed: int = 0, frame: int =
     # isolated dynamic pixels: a flow outlier of 10-30 px on a background pixel
     n_iso = 0
     for _ in range(n_isolated):
-        x, y = int(rng.integers(40, W - 40)), int(rng.integers(40, H - 40))
+        mg = min(40, W // 8, H // 8)
+        x, y = int(rng.integers(mg, W - mg)), int(rng.integers(mg, H - mg))
         if obj_id[y, x] >= 0:
             continue
         a = rng.uniform(0, 2 * np.pi)
