@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — stereo pairs/s of the scene-flow + cluster hot path at 1280x720 on N MI355X GPUs.
+
+A "step" is one pass of the whole hot path (mod_process_dev: fused scene-flow kernel -> dynamic mask -> windowed
+connected components -> per-cluster objects) over one batch of F synthetic 1280x720 stereo pairs that are already
+resident in HBM when the timed region starts.  Multi-GPU = frame sharding (weak scaling: every rank owns F pairs);
+the only collective is the RCCL broadcast of the camera-intrinsics/parameter block before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
+  roofline     — the dominant kernel group, priced with SURVEY.md §8(d)'s algorithmic bytes per pixel
+  cpu_baseline — the CPU oracle ("port": op-for-op restatement of the reference loops) timed on this box's host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0
+B_SCENE_FLOW = 40              # bytes/px: read disp_now 4 + disp_prev 4 + flow 8, write x,y,z,vx,vy,vz 24
+B_CLUSTER = 20                 # bytes/px: read z,vx,vy,vz 16, write label 4
+B_FUSED = 44                   # bytes/px: 16 in + 24 out + 4 label (mask never round-trips as a plane)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="stereo pairs per step and per GPU")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs generated per GPU (tiled to --frames)")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU (bounded sample)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cam, prm, batch, n_sample):
+    """Times the oracle on this box's host cores on the first n_sample pairs of rank 0's batch."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import pyoracle
+    pyoracle.lib()
+    n = min(n_sample, batch["disparity_now"].shape[0])
+
+    def one(f, mode):
+        ref = pyoracle.construct(cam, prm, batch["disparity_now"][f], batch["disparity_prev"][f], batch["flow"][f],
+                                 batch["t"][f], batch["q"][f], float(batch["dt"][f]), mode)
+        t1 = time.perf_counter()
+        lab, objs, K = pyoracle.cluster(ref["cloud"] if mode == "faithful" else ref, prm, mode)
+        return t1, ref, lab, objs
+
+    res = {}
+    refs = []
+    for mode in ("faithful", "tidy"):
+        sf = cl = 0.0
+        for f in range(n):
+            t0 = time.perf_counter()
+            t1, ref, lab, objs = one(f, mode)
+            t2 = time.perf_counter()
+            sf += t1 - t0
+            cl += t2 - t1
+            if mode == "tidy":
+                refs.append((ref, lab, objs))
+        res[mode] = {"scene_flow_ms": 1e3 * sf / n, "cluster_ms": 1e3 * cl / n, "pairs_per_s": n / (sf + cl)}
+    cores = os.cpu_count() or 1
+    workers = max(1, min(cores, 64))
+    reps = max(n, 2 * workers)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(workers) as ex:
+        list(ex.map(lambda f: one(f % n, "faithful")[0], range(reps)))
+    allcore = reps / (time.perf_counter() - t0)
+    out = {
+        "value": res["faithful"]["pairs_per_s"], "unit": "stereo pairs/s", "cores": 1, "kind": "port",
+        "sample": f"{n} of rank 0's 1280x720 pairs, oracle in 'faithful' mode (reference layouts, column-major walks, "
+                  f"per-frame allocations), single thread = what the reference uses for this path",
+        "ms_per_frame": {"scene_flow": res["faithful"]["scene_flow_ms"], "cluster": res["faithful"]["cluster_ms"]},
+        "tidy_1core": res["tidy"],
+        "all_cores": {"value": allcore, "threads": workers, "host_cores": cores, "mode": "faithful, frame-sharded"},
+    }
+    return out, refs
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd import dist as mdist
+    from moving_object_detector_amd.pipeline import PLANES, Context
+
+    W, H, F = args.width, args.height, args.frames
+    G = max(1, min(args.distinct, F))
+    # rank 0 owns the camera + dynamic_reconfigure parameters (reference defaults) and broadcasts them over RCCL
+    cam_s = prm_s = None
+    if rank == 0:
+        cam_s = capi.camera_struct(synth.make_camera(W, H))
+        prm_s = capi.params_struct(synth.Params())
+    cam_s, prm_s = mdist.broadcast_config(cam_s, prm_s, src=0, device=dev)
+
+    # synthetic pairs of this rank's shard (distinct seeds per rank), tiled to F frames at distinct HBM addresses
+    cam, host = synth.make_batch(W, H, G, seed=0, first_frame=rank * G)
+    idx = [i % G for i in range(F)]
+    d_now = torch.from_numpy(host["disparity_now"]).to(dev)[idx].contiguous()
+    d_prev = torch.from_numpy(host["disparity_prev"]).to(dev)[idx].contiguous()
+    flow = torch.from_numpy(host["flow"]).to(dev)[idx].contiguous()
+    ts, qs, dts = host["t"][idx], host["q"][idx], host["dt"][idx]
+
+    ctx = Context(W, H, max_frames=F, device=local_rank)
+    ctx.set_camera(cam_s)
+    ctx.set_params(prm_s)
+    ws = ctx.workspace(F)
+    batch = ctx.make_batch(d_now, d_prev, flow, ts, qs, dts)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.process(batch, ws)
+    torch.cuda.synchronize()
+    ctx.set_profiling(True)            # HIP events around each kernel group, on the stream the kernels run on
+    ctx.reset_stage_times()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.process(batch, ws)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage = {name: ctx.stage_time(i) for i, name in ((capi.MOD_STAGE_SCENE_FLOW, "scene_flow"), (capi.MOD_STAGE_CCL, "ccl"),
+                                                     (capi.MOD_STAGE_OBJECTS, "objects"))}
+    ctx.set_profiling(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        N = W * H
+        pairs = world * F * args.steps
+        value = pairs / elapsed
+        per_launch_ms = {k: (v[0] / v[1] if v[1] else float("nan")) for k, v in stage.items()}
+        sf_ms = per_launch_ms["scene_flow"]
+        cl_ms = per_launch_ms["ccl"] + per_launch_ms["objects"]
+        sf_gbs = F * N * B_SCENE_FLOW / (sf_ms * 1e-3) / 1e9
+        cl_gbs = F * N * B_CLUSTER / (cl_ms * 1e-3) / 1e9
+        dominant = "scene_flow" if sf_ms >= cl_ms else "cluster"
+        ach = sf_gbs if dominant == "scene_flow" else cl_gbs
+        roof = {
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_scene_flow_v4" if dominant == "scene_flow" else "cluster group (k_ccl_* + k_comp_stats..k_finalize)",
+            "algorithmic_bytes_per_px": B_SCENE_FLOW if dominant == "scene_flow" else B_CLUSTER,
+            "frames_per_launch": F, "avg_launch_ms": sf_ms if dominant == "scene_flow" else cl_ms,
+            "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
+            "groups": {
+                "scene_flow": {"ms_per_launch": sf_ms, "GBps": sf_gbs, "frac": sf_gbs / HBM_PEAK_GBS, "bytes_per_px": B_SCENE_FLOW},
+                "cluster": {"ms_per_launch": cl_ms, "GBps": cl_gbs, "frac": cl_gbs / HBM_PEAK_GBS, "bytes_per_px": B_CLUSTER,
+                            "ccl_ms": per_launch_ms["ccl"], "objects_ms": per_launch_ms["objects"]},
+                "fused_end_to_end": {"GBps": F * N * B_FUSED / ((sf_ms + cl_ms) * 1e-3) / 1e9, "bytes_per_px": B_FUSED},
+            },
+        }
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            prm = synth.Params()
+            cpu, refs = cpu_baseline(cam, prm, host, args.cpu_sample)
+            # same-run output check of the sampled pairs against the oracle
+            planes = ws["planes"][:, :len(refs)].cpu().numpy()
+            labels = ws["labels"][:len(refs)].cpu().numpy()
+            ok = True
+            for f, (ref, lab, objs) in enumerate(refs):
+                if f >= G:
+                    break
+                for i, k in enumerate(PLANES):
+                    a, r = planes[i, f], ref[k]
+                    ok &= bool(((a.view(np.uint32) == r.view(np.uint32)) | (np.isnan(a) & np.isnan(r))).all())
+                ok &= bool(np.array_equal(labels[f], lab))
+            cpu["gpu_outputs_match_oracle"] = ok
+        line = {
+            "metric": "stereo pairs/sec (scene-flow+cluster) at 1280x720", "value": value, "unit": "stereo pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_frame": 1e3 * elapsed / (args.steps * F), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
+            "config": {"workload": f"{W}x{H} synthetic sequence, scene-flow + cluster kernels only (disparity/flow precomputed, "
+                                   f"HBM-resident), reference default parameters",
+                       "frames_per_step_per_gpu": F, "distinct_frames_per_gpu": G, "sharding": f"frames x{world}",
+                       "collective": "one RCCL broadcast of the intrinsics/params block before the timed region"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
