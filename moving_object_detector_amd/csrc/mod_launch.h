@@ -16,11 +16,11 @@ struct SfArgs {
 struct ClArgs {
   const float *x, *y, *z, *vx, *vy, *vz;  // input planes [F][H][W]
   const uint64_t *mask;       // [F][H][mask_words] dynamic bits
-  uint64_t *edge_up;          // [F][H][mask_words] pixel has >=1 up-left edge (first_edge_key candidates)
-  uint64_t *edge_any;         // [F][H][mask_words] pixel has any edge (member of a labelled component)
+  uint64_t *lroot;            // [F][H][mask_words] pixel is the root of a tile-local component (owns a partial record)
   int32_t *parent;            // [F][N] union-find parents (only dynamic entries are ever touched)
+  int32_t *rootlist;          // [F][N] pixel indices of the final roots (aliases `members`, dead before k_relabel)
   int32_t *labels;            // [F][N] output plane; used as the root/code plane in between
-  CompRec *comps;             // [F][comp_cap]
+  CompRec *comps;             // [F][N] statistics records, indexed by the root's pixel index (sparsely touched)
   int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects, 3 overflow flags
   ClusterInfo *clusters;      // [F][max_objects]
   uint2 *members;             // [F][N] (norm bits, pixel index), grouped per cluster
@@ -28,7 +28,6 @@ struct ClArgs {
   void *objects;              // [F][max_objects] ModObject
   int32_t *n_objects;         // [F]
   int32_t *n_clusters;        // [F] or null
-  int32_t comp_cap;
   int32_t max_objects;
 };
 

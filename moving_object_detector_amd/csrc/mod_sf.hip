@@ -18,7 +18,7 @@ struct EventPair { hipEvent_t a, b; };
 struct Buffers {
   double *rayx = nullptr, *rayy = nullptr;
   FrameConst *fc = nullptr;                 // [maxF]
-  uint64_t *mask = nullptr, *edge_up = nullptr, *edge_any = nullptr;
+  uint64_t *mask = nullptr, *lroot = nullptr;
   int32_t *parent = nullptr;
   CompRec *comps = nullptr;
   int32_t *counters = nullptr;
@@ -43,7 +43,6 @@ struct ModContext {
   bool own_stream = false;
   DevCam dc{};
   Buffers b;
-  int comp_cap = 0;
   int max_objects = 0;
   size_t maxN = 0;
   int max_mask_words = 0;
@@ -204,10 +203,10 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster outputs labels, objects, n_objects are required");
   ClArgs a;
   a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
-  a.mask = mask; a.edge_up = c->b.edge_up; a.edge_any = c->b.edge_any; a.parent = c->b.parent;
+  a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.members;
   a.labels = out->labels; a.comps = c->b.comps; a.counters = c->b.counters; a.clusters = c->b.clusters;
   a.members = c->b.members; a.cursors = c->b.cursors; a.objects = out->objects; a.n_objects = out->n_objects;
-  a.n_clusters = out->n_clusters; a.comp_cap = c->comp_cap; a.max_objects = c->max_objects;
+  a.n_clusters = out->n_clusters; a.max_objects = c->max_objects;
   {
     StageTimer t(c, MOD_STAGE_CCL);
     if (!mask_ready) launch_dynamic_mask(c->dc, frames, pl->vx, pl->vy, pl->vz, (uint64_t *)mask, c->stream);
@@ -245,7 +244,6 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   c->maxN = N;
   c->max_mask_words = mod_mask_words(cfg->max_width);
   c->max_objects = cfg->max_objects > 0 ? cfg->max_objects : (int)std::max<size_t>(1, N / 100);
-  c->comp_cap = (int)(N / 2 + 1);
   if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
   else { if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return MOD_ERR_DEVICE; } c->own_stream = true; }
   const size_t mw = (size_t)F * cfg->max_height * c->max_mask_words;
@@ -254,10 +252,9 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   ok &= dalloc(&c->b.rayy, cfg->max_height + 4) == hipSuccess;
   ok &= dalloc(&c->b.fc, F) == hipSuccess;
   ok &= dalloc(&c->b.mask, mw) == hipSuccess;
-  ok &= dalloc(&c->b.edge_up, mw) == hipSuccess;
-  ok &= dalloc(&c->b.edge_any, mw) == hipSuccess;
+  ok &= dalloc(&c->b.lroot, mw) == hipSuccess;
   ok &= dalloc(&c->b.parent, (size_t)F * N) == hipSuccess;
-  ok &= dalloc(&c->b.comps, (size_t)F * c->comp_cap) == hipSuccess;
+  ok &= dalloc(&c->b.comps, (size_t)F * N) == hipSuccess;   // 32 B per pixel of address space, touched only at roots
   ok &= dalloc(&c->b.counters, (size_t)F * 8) == hipSuccess;
   ok &= dalloc(&c->b.clusters, (size_t)2 * F * c->max_objects) == hipSuccess;
   ok &= dalloc(&c->b.members, (size_t)F * N) == hipSuccess;
@@ -276,7 +273,7 @@ void mod_destroy(ModContext *c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
-  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.edge_up, b.edge_any, b.parent, b.comps, b.counters, b.clusters, b.members,
+  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.comps, b.counters, b.clusters, b.members,
                  b.cursors, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
