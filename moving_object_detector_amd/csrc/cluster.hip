@@ -14,10 +14,10 @@
 // has an up-left edge (that is where the serial scan creates the component's first — hence smallest — label).
 //
 // GPU formulation
-//   k_ccl_tile    one workgroup per 64 x TH tile: masked depth + parents live in LDS; rows are pre-linked into runs
-//                 with wave ballots (no atomics), the remaining window edges are united with LDS atomicMin hooks; the
-//                 tile's components leave as parent pointers + one partial statistics record per tile-local root.
-//   k_ccl_border  only the edges that cross a tile border, united in HBM (device-scope atomicMin).
+//   k_ccl_tile    one workgroup per 64 x TH tile + n-pixel halo: masked depth + parents live in LDS; rows are pre-linked
+//                 into runs with wave ballots (no atomics), the remaining window edges are united with LDS atomicMin
+//                 hooks (one per distinct pair per wave); the tile's components leave as atomicMin hooks on the HBM parent
+//                 plane (interior pixels AND the halo pixels they reach) + one partial statistics record per tile root.
 //   k_ccl_flatten root per pixel; tile-local records are folded into their global root's record; roots are listed.
 //   k_select      size filter + ordering by first_edge_key (the reference's numbering) + bbox/centre.
 //   k_relabel     final labels + per-cluster member segments; k_median: radix select of the median-||v|| member.
@@ -94,98 +94,175 @@ __device__ __forceinline__ void wave_accumulate(CompRec *recs, int rec_idx, uint
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Tile-local connected components.  Workgroup = 4 waves = one 64 x TH tile; wave w owns rows [w*TH/4, (w+1)*TH/4).
-template <int TH>
+// parent[p] = p for dynamic pixels (other entries are never read).  Runs before k_ccl_tile so that EVERY later write to
+// the parent plane can be an atomicMin hook — tiles may then unite pixels they do not own without ordering hazards.
+__global__ __launch_bounds__(256) void k_ccl_init(DevCam c, ClArgs a) {
+  const int lane = threadIdx.x, x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
+  if (y >= c.H) return;
+  const uint64_t w = a.mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x];
+  if ((w >> lane) & 1ull) {
+    const int p = y * c.W + x;
+    a.parent[(size_t)f * c.W * c.H + p] = p;
+  }
+}
+
+// LDS union-find over node ids: interior cells use their grid index, halo cells carry bit 15 so that they compare
+// larger than every interior cell — the root (minimum id) of any set that contains an interior pixel is interior.
+constexpr int kHaloBit = 0x8000;
+__device__ __forceinline__ int lds_find(const int *L, int a) {
+  int p = ld_relaxed(L + (a & 0x7fff));
+  while (p != a) { a = p; p = ld_relaxed(L + (a & 0x7fff)); }
+  return a;
+}
+__device__ __forceinline__ int lds_unite(int *L, int a, int b) {
+  while (true) {
+    a = lds_find(L, a);
+    b = lds_find(L, b);
+    if (a == b) return a;
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(&L[a & 0x7fff], b);
+    if (old == a) return b;
+    a = old;
+  }
+}
+
+// Unions of one window position for the whole wave.  Lanes of one run looking at one run above all hold the same
+// (cur, other) pair, so only the first lane of each contiguous group of equal pairs performs the union; all such
+// representatives run concurrently (LDS atomicMin hooks), then every lane that needed the union refreshes its root.
+// `last` remembers the label a lane was united with most recently: the neighbours in one window row nearly always
+// carry the same (possibly no longer root) label, and re-uniting them would cost a find each.
+__device__ __forceinline__ int lds_find_compress(int *L, int a) {
+  const int r = lds_find(L, a);
+  if (r != a && ld_relaxed(L + (a & 0x7fff)) != r) L[a & 0x7fff] = r;   // benign race: r is an ancestor of a
+  return r;
+}
+__device__ __forceinline__ void wave_unite_lds(int *L, bool need, int &cur, int &last, int other, int lane) {
+  if (__ballot(need) == 0) return;
+  const int pc = __shfl_up(cur, 1), po = __shfl_up(other, 1), pn = __shfl_up((int)need, 1);
+  const bool rep = need && !(lane > 0 && pn && pc == cur && po == other);
+  if (rep) lds_unite(L, cur, other);
+  if (need) { last = other; cur = lds_find_compress(L, cur); }
+}
+
+// Tile-local connected components INCLUDING the edges that leave the tile.
+// Workgroup = 4 waves = one 64 x TH tile plus an n-pixel halo above and to the left (masked depth + parents in LDS).
+//   A  cooperative load of the (TH+n) x (64+n) grid; rows pre-linked into runs with wave ballots (no atomics)
+//   B  the rest of each pixel's up-left window: (n+1) batched LDS reads per window row, unions deduplicated per wave
+//   C  publish: interior pixels hook onto their tile root, linked halo pixels are united with it in HBM (atomicMin
+//      only), tile roots get an empty statistics record
+//   D  partial statistics (size, first_edge_key, bbox) of the tile's components, one set of atomics per (wave, root)
+template <int TH, int NMAX>
 __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   constexpr int RPW = TH / 4;                       // rows per wave
-  __shared__ float zt[TH * 64];
-  __shared__ int Lt[TH * 64];
-  __shared__ uint64_t mrow[TH];
+  constexpr int PW = 64 + NMAX, PH = TH + NMAX, G = PW * PH;
+  __shared__ float zt[G];
+  __shared__ int Lt[G];
+  __shared__ uint64_t m0[PH], mL[PH];
   __shared__ int s_any;
   const int lane = threadIdx.x, w = threadIdx.y, tid = w * 64 + lane;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
+  const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
   const int MW = c.mask_words, n = c.n;
   const size_t N = (size_t)c.W * c.H;
   const size_t fN = (size_t)f * N;
   if (tid == 0) s_any = 0;
   __syncthreads();
-  if (tid < TH) {
-    const int gy = y0 + tid;
-    const uint64_t m = (gy < c.H) ? a.mask[((size_t)f * c.H + gy) * MW + blockIdx.x] : 0ull;
-    mrow[tid] = m;
-    if (m) s_any = 1;
+  if (tid < PH) {
+    const int gy = y0 - NMAX + tid;
+    const bool inrow = gy >= 0 && gy < c.H && tid >= NMAX - n;
+    const uint64_t *mr = a.mask + ((size_t)f * c.H + (inrow ? gy : 0)) * MW;
+    const uint64_t v0 = inrow ? mr[wi] : 0ull;
+    m0[tid] = v0;
+    mL[tid] = (inrow && wi > 0) ? mr[wi - 1] : 0ull;
+    if (tid >= NMAX && v0) s_any = 1;
   }
   __syncthreads();
   const int r0 = w * RPW;
-  if (!s_any) {                                     // nothing dynamic in the tile: only the root bits need clearing
+  if (!s_any) {                                     // nothing dynamic inside the tile: only the root bits need clearing
     if (lane == 0)
-      for (int j = 0; j < RPW; j++) if (y0 + r0 + j < c.H) a.lroot[((size_t)f * c.H + y0 + r0 + j) * MW + blockIdx.x] = 0ull;
+      for (int j = 0; j < RPW; j++) if (y0 + r0 + j < c.H) a.lroot[((size_t)f * c.H + y0 + r0 + j) * MW + wi] = 0ull;
     return;
   }
   const float th = c.depth_th;
-  float zr[RPW];
+  int *parent = a.parent + fN;
+  // ---- phase A: masked depth + identity parents for the grid ---------------------------------------------------
+  for (int cell = tid; cell < G; cell += 256) {
+    const int gr = cell / PW, gc = cell - gr * PW;
+    const int gy = y0 - NMAX + gr, gx = x0 - NMAX + gc;
+    const bool interior = gr >= NMAX && gc >= NMAX;
+    const bool used = gr >= NMAX - n && gc >= NMAX - n && gx >= 0;   // rows outside the image have empty mask words
+    const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
+    const bool dyn = used && ((mw >> (gx & 63)) & 1ull);
+    zt[cell] = dyn ? a.z[fN + (size_t)gy * c.W + gx] : 0.0f;
+    Lt[cell] = interior ? cell : (cell | kHaloBit);
+  }
+  __syncthreads();
   bool upr[RPW];
-  // ---- phase A: masked depth into LDS, horizontal runs by ballot --------------------------------------------
 #pragma unroll
-  for (int j = 0; j < RPW; j++) {
-    const int rr = r0 + j;
-    const uint64_t mw = mrow[rr];
+  for (int j = 0; j < RPW; j++) {                   // horizontal runs of the wave's rows
+    const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
+    const uint64_t mw = m0[rr + NMAX];
     const bool dyn = (mw >> lane) & 1ull;
-    const float z = dyn ? a.z[fN + (size_t)(y0 + rr) * c.W + x0 + lane] : 0.0f;
-    zr[j] = z;
-    zt[rr * 64 + lane] = z;
+    const float z = zt[me];
     const float zl = __shfl_up(z, 1);
     const bool cl = dyn && lane > 0 && ((mw >> (lane - 1)) & 1ull) && !(fabsf(z - zl) > th);   // linked to the left neighbour
     const uint64_t C = __ballot(cl);
     const uint64_t starts = mw & ~C;                // run starts: dynamic and not linked to the left
     if (dyn) {
       const int s = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
-      Lt[rr * 64 + lane] = rr * 64 + s;
+      Lt[me] = me - lane + s;
     }
     upr[j] = cl;
   }
   __syncthreads();
-  // ---- phase B: the rest of the up-left window, in-tile edges only ------------------------------------------
+  // ---- phase B: the rest of the up-left window ---------------------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j;
-    const bool dyn = (mrow[rr] >> lane) & 1ull;
-    if (!dyn) continue;
-    const float zp = zr[j];
-    const int me = rr * 64 + lane;
-    int cur = Lt[me];
+    const uint64_t mw = m0[rr + NMAX];
+    if (mw == 0) continue;                           // wave-uniform
+    const bool dyn = (mw >> lane) & 1ull;
+    const int me = (rr + NMAX) * PW + NMAX + lane;
+    const float zp = zt[me];
+    int cur = dyn ? ld_relaxed(&Lt[me]) : -1, last = -1;
     bool up = upr[j];
-    for (int dv = -n; dv <= 0; dv++) {
-      const int qr = rr + dv;
-      if (qr < 0) continue;
-      const uint64_t mq = mrow[qr];
-      for (int du = -n; du <= 0; du++) {
-        const int qc = lane + du;
-        if (qc < 0 || (dv == 0 && du >= -1)) continue;      // (0,0) is p itself, (0,-1) is the run link
-        if (!((mq >> qc) & 1ull)) continue;
-        const int qi = qr * 64 + qc;
-        if (fabsf(zp - zt[qi]) > th) continue;               // depthDiff gate (clusterer_nodelet.cpp:194); NaN links
-        up = true;
-        const int rq = ld_relaxed(&Lt[qi]);
-        if (rq != cur) cur = uf_unite(Lt, cur, rq);
+    for (int dv = 0; dv <= n; dv++) {
+      const int qg = rr + NMAX - dv;                 // grid row of the window row
+      const uint64_t q0 = m0[qg], qL = mL[qg];
+      if ((q0 | qL) == 0) continue;                  // wave-uniform
+      const int base = qg * PW + NMAX + lane;
+      float zq[NMAX + 1];
+      int lq[NMAX + 1];
+#pragma unroll
+      for (int k = 0; k <= NMAX; k++) { zq[k] = zt[base - k]; lq[k] = ld_relaxed(&Lt[base - k]); }
+#pragma unroll
+      for (int k = 0; k <= NMAX; k++) {
+        if (dv == 0 && k == 0) continue;
+        const int qc = lane - k;
+        const bool bit = (qc >= 0) ? ((q0 >> qc) & 1ull) : ((qL >> (64 + qc)) & 1ull);
+        // (0,-1) inside the wave is the run link of phase A; across the tile edge (lane 0) it is an ordinary edge
+        const bool runlink = (dv == 0 && k == 1 && qc >= 0);
+        const bool valid = dyn && k <= n && bit && !runlink && !(fabsf(zp - zq[k]) > th);   // depthDiff gate (:194); NaN links
+        up = up || valid;
+        if (!(c.debug & 1)) wave_unite_lds(Lt, valid && lq[k] != cur && lq[k] != last, cur, last, lq[k], lane);
       }
     }
     upr[j] = up;
   }
   __syncthreads();
-  // ---- phase C: flatten inside the tile, publish parents, root bits and empty records ------------------------
+  // ---- phase C: publish -----------------------------------------------------------------------------------------------
   int rootg[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, gy = y0 + rr;
-    const bool dyn = (mrow[rr] >> lane) & 1ull;
+    const bool dyn = (m0[rr + NMAX] >> lane) & 1ull;
     int rg = -1;
     bool isroot = false;
     if (dyn) {
-      const int me = rr * 64 + lane;
-      const int r = uf_find(Lt, me);
-      rg = (y0 + (r >> 6)) * c.W + x0 + (r & 63);
-      a.parent[fN + (size_t)gy * c.W + x0 + lane] = rg;
+      const int me = (rr + NMAX) * PW + NMAX + lane;
+      const int r = lds_find(Lt, me);                // interior by construction
+      const int rgr = r / PW, rgc = r - rgr * PW;
+      rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
+      const int gp = gy * c.W + x0 + lane;
       isroot = (r == me);
       if (isroot) {
         CompRec rec;
@@ -193,76 +270,53 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
         rec.mn[0] = rec.mn[1] = rec.mn[2] = 0xffffffffu;
         rec.mx[0] = rec.mx[1] = rec.mx[2] = 0u;
         a.comps[fN + rg] = rec;
+      } else {
+        if (c.debug & 4) parent[gp] = rg;
+        else {
+          const int old = atomicMin(&parent[gp], rg);
+          if (old != gp) uf_unite(parent, old, rg);
+        }    // a neighbouring tile had already hooked p: keep both links
       }
     }
     rootg[j] = rg;
     const uint64_t rb = __ballot(isroot);
-    if (lane == 0 && gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + blockIdx.x] = rb;
+    if (lane == 0 && gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + wi] = rb;
+  }
+  // halo pixels that ended up in a tile component: unite them (they belong to other tiles) with the tile root in HBM
+  if (!(c.debug & 2)) {
+    const int topcells = n * (64 + n);               // n rows x (n + 64) columns above the tile
+    const int total = topcells + TH * n;             // + TH rows x n columns left of it
+    for (int i = tid; i < total; i += 256) {
+      int gr, gc;
+      if (i < topcells) { gr = NMAX - n + i / (64 + n); gc = NMAX - n + i % (64 + n); }
+      else { const int t = i - topcells; gr = NMAX + t / n; gc = NMAX - n + t % n; }
+      const int cell = gr * PW + gc;
+      const int gx = x0 - NMAX + gc;
+      const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
+      if (gx < 0 || !((mw >> (gx & 63)) & 1ull)) continue;
+      const int hid = cell | kHaloBit;
+      const int r = lds_find(Lt, hid);
+      if (r == hid) continue;                         // not linked into the tile
+      const int rgr = r / PW, rgc = r - rgr * PW;
+      const int rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
+      const int hg = (y0 - NMAX + gr) * c.W + gx;
+      uf_unite(parent, hg, rg);
+    }
   }
   __syncthreads();   // record initialisation has reached L2 before any wave's atomics on it
-  // ---- phase D: partial statistics of the tile's components -----------------------------------------------------
+  // ---- phase D: partial statistics of the tile's components ---------------------------------------------------------
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, gy = y0 + rr;
-    if (mrow[rr] == 0) continue;                     // wave-uniform
+    if (m0[rr + NMAX] == 0 || (c.debug & 8)) continue;                // wave-uniform
     const int rg = rootg[j];
     uint32_t ox = 0, oy = 0, oz = 0, key = (uint32_t)kKeyNone;
     if (rg >= 0) {
       const size_t gp = (size_t)gy * c.W + x0 + lane;
-      ox = f2ord(a.x[fN + gp]); oy = f2ord(a.y[fN + gp]); oz = f2ord(zr[j]);
+      ox = f2ord(a.x[fN + gp]); oy = f2ord(a.y[fN + gp]); oz = f2ord(zt[(rr + NMAX) * PW + NMAX + lane]);
       if (upr[j]) key = (uint32_t)gp;
     }
     wave_accumulate(a.comps + fN, rg, key, ox, oy, oz, lane);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Edges that leave the tile (to the tile on the left, above, or above-left).  Thread = pixel, wave = one mask word.
-template <int TH>
-__global__ __launch_bounds__(256) void k_ccl_border(DevCam c, ClArgs a) {
-  const int lane = threadIdx.x, wi = blockIdx.x, x = wi * 64 + lane, y = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
-  if (y >= c.H) return;
-  const int MW = c.mask_words, n = c.n;
-  const uint64_t *mf = a.mask + (size_t)f * c.H * MW;
-  const uint64_t mword = mf[(size_t)y * MW + wi];
-  if (mword == 0) return;
-  const int tr = y % TH;                             // row inside the tile band
-  const bool dyn = (mword >> lane) & 1ull;
-  const bool work = dyn && (tr < n || lane < n);
-  if (__ballot(work) == 0) return;
-  if (!work) return;
-  const size_t N = (size_t)c.W * c.H;
-  const float *zf = a.z + (size_t)f * N;
-  int *parent = a.parent + (size_t)f * N;
-  const int p = y * c.W + x;
-  const float zp = zf[p];
-  int cur = ld_relaxed(parent + p);
-  bool up = false;
-  for (int dv = -n; dv <= 0; dv++) {
-    const int yy = y + dv;
-    if (yy < 0) continue;
-    const bool above = dv < -tr;                     // row yy lies in the band above
-    const uint64_t w0 = mf[(size_t)yy * MW + wi];
-    const uint64_t wm = (wi > 0) ? mf[(size_t)yy * MW + wi - 1] : 0ull;
-    for (int du = -n; du <= 0; du++) {
-      if (dv == 0 && du == 0) continue;
-      const int qc = lane + du;                      // column relative to the tile
-      if (!(above || qc < 0)) continue;              // in-tile edge: k_ccl_tile did it
-      const int xx = x + du;
-      if (xx < 0) continue;
-      const uint64_t wq = (qc >= 0) ? w0 : wm;
-      if (!((wq >> (xx & 63)) & 1ull)) continue;
-      const int q = yy * c.W + xx;
-      if (fabsf(zp - zf[q]) > c.depth_th) continue;
-      up = true;
-      const int rq = ld_relaxed(parent + q);
-      if (rq != cur) cur = uf_unite(parent, cur, rq);
-    }
-  }
-  if (up) {
-    // p has an up-left edge: candidate for first_edge_key.  parent[p] always names a tile-local root, whose record is
-    // folded into the final root's record by k_ccl_flatten.
-    atomicMin(&a.comps[(size_t)f * N + ld_relaxed(parent + p)].key, p);
   }
 }
 
@@ -492,10 +546,12 @@ constexpr int kTileH = 16;
 
 void launch_ccl(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   dim3 block(64, 4, 1);
-  dim3 tgrid(c.mask_words, (c.H + kTileH - 1) / kTileH, frames);
-  hipLaunchKernelGGL(k_ccl_tile<kTileH>, tgrid, block, 0, s, c, a);
   dim3 grid(c.mask_words, (c.H + 3) / 4, frames);
-  hipLaunchKernelGGL(k_ccl_border<kTileH>, grid, block, 0, s, c, a);
+  dim3 tgrid(c.mask_words, (c.H + kTileH - 1) / kTileH, frames);
+  hipLaunchKernelGGL(k_ccl_init, grid, block, 0, s, c, a);
+  if (c.n <= 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4>), tgrid, block, 0, s, c, a);
+  else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8>), tgrid, block, 0, s, c, a);
+  else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16>), tgrid, block, 0, s, c, a);
   hipLaunchKernelGGL(k_ccl_flatten, grid, block, 0, s, c, a);
 }
 

@@ -14,6 +14,7 @@ struct DevCam {
   int32_t mask_words;      // ceil(W/64)
   int32_t n;               // neighbor_distance
   int32_t cluster_size;
+  int32_t debug;           // MOD_DEBUG experiment bits (0 in production): timing ablations only, results become wrong
   float fT;                // F32(f * T)                       disparity_image_processor.cpp:44
   float dmin, dmax;        // min/max_disparity                disparity_image_processor.cpp:25-27
   float flow_th;           // (float)dynamic_flow_diff         scene_flow_constructor.cpp:198

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -105,6 +106,7 @@ void refresh_devcam(ModContext *c) {
   d.mask_words = mod_mask_words(d.W);
   d.n = c->prm.neighbor_distance;
   d.cluster_size = c->prm.cluster_size;
+  { const char *e = getenv("MOD_DEBUG"); d.debug = e ? atoi(e) : 0; }
   d.fT = c->cam.disp_f * c->cam.disp_T;               // F32 product, exactly the reference's `focal_length * baseline`
   d.dmin = c->cam.min_disparity; d.dmax = c->cam.max_disparity;
   d.flow_th = (float)c->prm.dynamic_flow_diff;
