@@ -455,46 +455,137 @@ __global__ __launch_bounds__(256) void k_relabel(DevCam c, ClArgs a) {
 }
 
 // Median-velocity member per cluster: the element at position size/2 of the members sorted by ||v|| descending
-// (clusterer_nodelet.cpp:168-174) == radix select on the F32 bits (all norms are finite and >= 0).
-__global__ __launch_bounds__(256) void k_median(DevCam c, ClArgs a) {
-  const int f = blockIdx.y, tid = threadIdx.x;
+// (clusterer_nodelet.cpp:168-174).  All norms are finite and >= 0, so their F32 bit patterns order like the values:
+// a range-adaptive 2048-bin histogram over (bits - min) >> shift isolates the bin that holds rank size/2, its members
+// (a handful) are ranked exactly in LDS; degenerate distributions narrow the range and repeat.
+constexpr int kMedThreads = 1024, kMedBins = 2048, kMedCap = 2048, kMedBatch = 8;
+
+__global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t N = (size_t)c.W * c.H;
   const int K = a.counters[f * 8 + 1];
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t s_prefix, s_rem;
+  __shared__ uint32_t hist[kMedBins];
+  __shared__ uint2 cand[kMedCap];
+  __shared__ uint32_t s_red[2][16];
+  __shared__ uint32_t s_lo, s_hi, s_bin, s_rem, s_cnt, s_val;
   __shared__ unsigned long long s_best;
   __shared__ int s_amb;
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
     ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
     const int size = ci->size;
     const uint2 *seg = a.members + (size_t)f * N + ci->offset;
-    uint32_t prefix = 0, pmask = 0, rem = (uint32_t)(size / 2);
-    for (int pass = 0; pass < 4; pass++) {
-      const int shift = 24 - 8 * pass;
-      hist[tid] = 0;
-      __syncthreads();
-      for (int i = tid; i < size; i += 256) {
-        const uint32_t b = seg[i].x;
-        if ((b & pmask) == prefix) atomicAdd(&hist[(b >> shift) & 255u], 1u);
-      }
-      __syncthreads();
-      if (tid == 0) {
-        uint32_t r = rem;
-        int bin = 255;
-        for (; bin > 0; bin--) { if (r < hist[bin]) break; r -= hist[bin]; }
-        s_prefix = prefix | ((uint32_t)bin << shift);
-        s_rem = r;
-      }
-      __syncthreads();
-      prefix = s_prefix; rem = s_rem; pmask |= 255u << shift;
-      __syncthreads();
+    // ---- scan 1: value range ----
+    uint32_t mn = 0xffffffffu, mx = 0u;
+    for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
+      uint32_t v[kMedBatch];
+#pragma unroll
+      for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? seg[i].x : 0xffffffffu; }
+#pragma unroll
+      for (int u = 0; u < kMedBatch; u++) if (v[u] != 0xffffffffu) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
     }
-    // candidates: members whose norm equals the selected value; canonical pick = smallest column-major index
+    mn = wave_min_u32(mn); mx = wave_max_u32(mx);
+    if (lane == 0) { s_red[0][wv] = mn; s_red[1][wv] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t lo = 0xffffffffu, hi = 0u;
+      for (int i = 0; i < kMedThreads / 64; i++) { lo = s_red[0][i] < lo ? s_red[0][i] : lo; hi = s_red[1][i] > hi ? s_red[1][i] : hi; }
+      s_lo = lo; s_hi = hi; s_rem = (uint32_t)(size / 2);
+    }
+    __syncthreads();
+    uint32_t lo = s_lo, hi = s_hi, rem = s_rem;
+    bool exact = false;                      // the live range is a single value: every member of it ties
+    bool in_lds = false;                     // the live range has been copied to `cand`
+    int cn = 0;
+    uint32_t val = 0;
+    while (true) {
+      const uint32_t range = hi - lo;
+      const int shift = range < (uint32_t)kMedBins ? 0 : (32 - __clz((int)range) - 11);   // (range >> shift) < 2048
+      // ---- histogram of the live range (from HBM until it fits the LDS list, then from LDS) ----
+      for (int i = tid; i < kMedBins; i += kMedThreads) hist[i] = 0;
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+      if (!in_lds) {
+        for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
+          uint32_t v[kMedBatch];
+#pragma unroll
+          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? seg[i].x : 0xffffffffu; }
+#pragma unroll
+          for (int u = 0; u < kMedBatch; u++) if (v[u] >= lo && v[u] <= hi) atomicAdd(&hist[(v[u] - lo) >> shift], 1u);
+        }
+      } else {
+        for (int i = tid; i < cn; i += kMedThreads) { const uint32_t b = cand[i].x; if (b >= lo && b <= hi) atomicAdd(&hist[(b - lo) >> shift], 1u); }
+      }
+      __syncthreads();
+      // ---- bin that holds descending rank `rem`: wave 0, lane l owns bins [2047-32l-31, 2047-32l] ----
+      if (wv == 0) {
+        uint32_t sum = 0;
+        const int top = kMedBins - 1 - 32 * lane;
+        for (int j = 0; j < 32; j++) sum += hist[top - j];
+        uint32_t incl = sum;                                      // inclusive prefix over lanes (= bins from the top)
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        const uint32_t excl = incl - sum;
+        if (rem >= excl && rem < incl) {
+          uint32_t r = rem - excl;
+          int bin = top;
+          for (int j = 0; j < 32; j++, bin--) { const uint32_t h = hist[bin]; if (r < h) break; r -= h; }
+          s_bin = (uint32_t)bin; s_rem = r;
+        }
+      }
+      __syncthreads();
+      const uint32_t bin = s_bin, inbin = hist[bin];
+      rem = s_rem;
+      const uint32_t nlo = lo + (bin << shift);
+      const uint32_t nhi = shift ? (nlo + ((1u << shift) - 1u)) : nlo;
+      lo = nlo; hi = nhi < hi ? nhi : hi;
+      if (shift == 0) { exact = true; val = lo; break; }
+      if (in_lds && inbin <= 64u) break;                            // rank the few survivors directly
+      __syncthreads();                                              // hist / s_cnt are rewritten below
+      if (!in_lds && inbin <= (uint32_t)kMedCap) {                  // copy the live range into LDS once it fits
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
+          uint2 v[kMedBatch];
+#pragma unroll
+          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? seg[i] : make_uint2(0xffffffffu, 0u); }
+#pragma unroll
+          for (int u = 0; u < kMedBatch; u++)
+            if (v[u].x >= lo && v[u].x <= hi) { const uint32_t slot = atomicAdd(&s_cnt, 1u); cand[slot] = v[u]; }
+        }
+        __syncthreads();
+        cn = (int)s_cnt;
+        in_lds = true;
+        if (cn <= 64) break;
+        __syncthreads();
+      }
+    }
+    if (!exact) {
+      // ---- exact rank among the (<= 64) members left in [lo, hi]: compact them (hist is free now), then count ----
+      __syncthreads();
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+      for (int i = tid; i < cn; i += kMedThreads) {
+        const uint32_t b = cand[i].x;
+        if (b >= lo && b <= hi) hist[atomicAdd(&s_cnt, 1u)] = b;
+      }
+      __syncthreads();
+      const int fn = (int)s_cnt;
+      if (tid < fn) {
+        const uint32_t b = hist[tid];
+        uint32_t gt = 0, ge = 0;
+        for (int j = 0; j < fn; j++) { const uint32_t o = hist[j]; gt += o > b; ge += o >= b; }
+        if (gt <= rem && rem < ge) s_val = b;                       // every member of that value writes the same bits
+      }
+      __syncthreads();
+      val = s_val;
+    }
+    // ---- ties: canonical pick = smallest column-major index; flag ties between different vectors ----
     if (tid == 0) { s_best = ~0ull; s_amb = 0; }
     __syncthreads();
-    for (int i = tid; i < size; i += 256) {
-      const uint2 m = seg[i];
-      if (m.x == prefix) {
+    const bool from_lds = in_lds;
+    const int tn = from_lds ? cn : size;
+    for (int i = tid; i < tn; i += kMedThreads) {
+      const uint2 m = from_lds ? cand[i] : seg[i];
+      if (m.x == val) {
         const uint32_t px = m.y % (uint32_t)c.W, py = m.y / (uint32_t)c.W;
         atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | m.y);
       }
@@ -502,9 +593,9 @@ __global__ __launch_bounds__(256) void k_median(DevCam c, ClArgs a) {
     __syncthreads();
     const uint32_t best = (uint32_t)(s_best & 0xffffffffull);
     const float bvx = a.vx[(size_t)f * N + best], bvy = a.vy[(size_t)f * N + best], bvz = a.vz[(size_t)f * N + best];
-    for (int i = tid; i < size; i += 256) {
-      const uint2 m = seg[i];
-      if (m.x == prefix && m.y != best) {
+    for (int i = tid; i < tn; i += kMedThreads) {
+      const uint2 m = from_lds ? cand[i] : seg[i];
+      if (m.x == val && m.y != best) {
         const size_t q = (size_t)f * N + m.y;
         if (__float_as_uint(a.vx[q]) != __float_as_uint(bvx) || __float_as_uint(a.vy[q]) != __float_as_uint(bvy) ||
             __float_as_uint(a.vz[q]) != __float_as_uint(bvz)) s_amb = 1;
@@ -512,7 +603,7 @@ __global__ __launch_bounds__(256) void k_median(DevCam c, ClArgs a) {
     }
     __syncthreads();
     if (tid == 0) {
-      ci->med_pix = (int)best; ci->med_bits = prefix; ci->ambiguous = s_amb;
+      ci->med_pix = (int)best; ci->med_bits = val; ci->ambiguous = s_amb;
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
       o->velocity[0] = (double)bvx; o->velocity[1] = (double)bvy; o->velocity[2] = (double)bvz;
     }
@@ -561,6 +652,6 @@ void launch_objects(const DevCam &c, const ClArgs &a, int frames, hipStream_t s)
   ClusterInfo *tmp = a.clusters + (size_t)frames * a.max_objects;
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
   hipLaunchKernelGGL(k_relabel, grid, block, 0, s, c, a);
-  hipLaunchKernelGGL(k_median, dim3(16, frames), dim3(256), 0, s, c, a);
+  hipLaunchKernelGGL(k_median, dim3(16, frames), dim3(kMedThreads), 0, s, c, a);
   hipLaunchKernelGGL(k_finalize, dim3((frames + 63) / 64), dim3(64), 0, s, c, a, frames);
 }
