@@ -58,13 +58,30 @@ __device__ __forceinline__ int uf_unite(int *parent, int a, int b) {
   }
 }
 
+// Wave-wide min/max: four DPP steps reduce each row of 16 lanes (quad swaps, half-row mirror, row mirror), four
+// v_readlane + scalar ops combine the rows.  All 64 lanes must be active.  ~11 instructions, no LDS traffic.
+#define MOD_DPP(v, ctrl) (uint32_t) __builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, 0xF, 0xF, false)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t < v ? t : v; }
-  return v;
+  uint32_t t;
+  t = MOD_DPP(v, 0xB1); v = t < v ? t : v;     // quad_perm [1,0,3,2]
+  t = MOD_DPP(v, 0x4E); v = t < v ? t : v;     // quad_perm [2,3,0,1]
+  t = MOD_DPP(v, 0x141); v = t < v ? t : v;    // row_half_mirror
+  t = MOD_DPP(v, 0x140); v = t < v ? t : v;    // row_mirror
+  const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
-  return v;
+  uint32_t t;
+  t = MOD_DPP(v, 0xB1); v = t > v ? t : v;
+  t = MOD_DPP(v, 0x4E); v = t > v ? t : v;
+  t = MOD_DPP(v, 0x141); v = t > v ? t : v;
+  t = MOD_DPP(v, 0x140); v = t > v ? t : v;
+  const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
 }
 
 // Adds the members of one wave (grouped by the record they belong to) into the statistics records with one set of
@@ -93,25 +110,18 @@ __device__ __forceinline__ void wave_accumulate(CompRec *recs, int rec_idx, uint
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// parent[p] = p for dynamic pixels (other entries are never read).  Runs before k_ccl_tile so that EVERY later write to
-// the parent plane can be an atomicMin hook — tiles may then unite pixels they do not own without ordering hazards.
-__global__ __launch_bounds__(256) void k_ccl_init(DevCam c, ClArgs a) {
-  const int lane = threadIdx.x, x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
-  if (y >= c.H) return;
-  const uint64_t w = a.mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x];
-  if ((w >> lane) & 1ull) {
-    const int p = y * c.W + x;
-    a.parent[(size_t)f * c.W * c.H + p] = p;
-  }
-}
-
 // LDS union-find over node ids: interior cells use their grid index, halo cells carry bit 15 so that they compare
 // larger than every interior cell — the root (minimum id) of any set that contains an interior pixel is interior.
 constexpr int kHaloBit = 0x8000;
-__device__ __forceinline__ int lds_find(const int *L, int a) {
+__device__ __forceinline__ int lds_find(int *L, int a) {
+  // path halving with plain stores: only non-root cells are rewritten, and only with one of their ancestors, so a
+  // racing atomicMin hook (which re-examines the value it displaced) never loses a link
   int p = ld_relaxed(L + (a & 0x7fff));
-  while (p != a) { a = p; p = ld_relaxed(L + (a & 0x7fff)); }
+  while (p != a) {
+    const int g = ld_relaxed(L + (p & 0x7fff));
+    if (g != p) L[a & 0x7fff] = g;
+    a = p; p = g;
+  }
   return a;
 }
 __device__ __forceinline__ int lds_unite(int *L, int a, int b) {
@@ -158,13 +168,16 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   __shared__ float zt[G];
   __shared__ int Lt[G];
   __shared__ uint64_t m0[PH], mL[PH];
-  __shared__ int s_any;
+  constexpr int kSlots = 32;
+  __shared__ int s_any, s_nreq, s_nslots;
+  __shared__ CompRec srec[kSlots];
+  __shared__ int sroot[kSlots];
   const int lane = threadIdx.x, w = threadIdx.y, tid = w * 64 + lane;
   const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
   const int MW = c.mask_words, n = c.n;
   const size_t N = (size_t)c.W * c.H;
   const size_t fN = (size_t)f * N;
-  if (tid == 0) s_any = 0;
+  if (tid == 0) { s_any = 0; s_nreq = 0; s_nslots = 0; }
   __syncthreads();
   if (tid < PH) {
     const int gy = y0 - NMAX + tid;
@@ -177,28 +190,36 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   }
   __syncthreads();
   const int r0 = w * RPW;
-  if (!s_any) {                                     // nothing dynamic inside the tile: only the root bits need clearing
-    if (lane == 0)
-      for (int j = 0; j < RPW; j++) if (y0 + r0 + j < c.H) a.lroot[((size_t)f * c.H + y0 + r0 + j) * MW + wi] = 0ull;
+  int *hdr = a.tilehdr + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * 2;
+  if (!s_any) {                                     // nothing dynamic inside the tile
+    if (tid == 0) { hdr[0] = 0; hdr[1] = 0; }
     return;
   }
   const float th = c.depth_th;
-  int *parent = a.parent + fN;
-  // ---- phase A: masked depth + identity parents for the grid ---------------------------------------------------
-  for (int cell = tid; cell < G; cell += 256) {
-    const int gr = cell / PW, gc = cell - gr * PW;
-    const int gy = y0 - NMAX + gr, gx = x0 - NMAX + gc;
-    const bool interior = gr >= NMAX && gc >= NMAX;
-    const bool used = gr >= NMAX - n && gc >= NMAX - n && gx >= 0;   // rows outside the image have empty mask words
-    const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
-    const bool dyn = used && ((mw >> (gx & 63)) & 1ull);
-    zt[cell] = dyn ? a.z[fN + (size_t)gy * c.W + gx] : 0.0f;
-    Lt[cell] = interior ? cell : (cell | kHaloBit);
+  const bool prof = c.debug & 128;
+  unsigned long long t0 = prof ? clock64() : 0, t1;
+#define STAMP(i) if (prof) { t1 = clock64(); if (lane == 0) { atomicAdd(&a.dbg[i], t1 - t0); atomicMax(&a.dbg[16 + i], t1 - t0); } t0 = t1; }
+  // ---- phase A: masked depth + identity parents; grid row gr = image row y0 - NMAX + gr, 4 rows per step -----------
+  for (int gr = w; gr < PH; gr += 4) {
+    const uint64_t q0 = m0[gr], qL = mL[gr];          // zero for rows that are unused or outside the image
+    const size_t rowp = fN + (size_t)(y0 - NMAX + gr) * c.W + x0;
+    const int cell = gr * PW + NMAX + lane;
+    const bool d = (q0 >> lane) & 1ull;
+    zt[cell] = d ? a.z[rowp + lane] : 0.0f;
+    Lt[cell] = (gr >= NMAX) ? cell : (cell | kHaloBit);
+    if (lane < n) {                                   // left halo: column x0 - 1 - lane
+      const int hc = gr * PW + NMAX - 1 - lane;
+      const bool dl = (qL >> (63 - lane)) & 1ull;
+      zt[hc] = dl ? a.z[rowp - 1 - lane] : 0.0f;
+      Lt[hc] = hc | kHaloBit;
+    }
   }
   __syncthreads();
+  STAMP(0)
+  // ---- phase A1: horizontal runs of the wave's rows by ballot (no atomics) ---------------------------------------------
   bool upr[RPW];
 #pragma unroll
-  for (int j = 0; j < RPW; j++) {                   // horizontal runs of the wave's rows
+  for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX];
     const bool dyn = (mw >> lane) & 1ull;
@@ -214,7 +235,29 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     upr[j] = cl;
   }
   __syncthreads();
-  // ---- phase B: the rest of the up-left window ---------------------------------------------------------------------
+  // ---- phase A2: vertical pre-link (the pixel straight above), one union per distinct (run, run-above) pair -----------
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
+    const uint64_t mw = m0[rr + NMAX], mu = m0[rr + NMAX - 1];
+    if ((mw & mu) == 0) continue;                    // wave-uniform
+    const bool v = ((mw & mu) >> lane) & 1ull;
+    const bool link = v && !(fabsf(zt[me] - zt[me - PW]) > th);
+    int cur = ld_relaxed(&Lt[me]), last = -1;
+    wave_unite_lds(Lt, link, cur, last, ld_relaxed(&Lt[me - PW]), lane);
+    upr[j] = upr[j] || link;
+  }
+  __syncthreads();
+  // ---- phase A3: flatten, so that phase B can compare labels directly ----------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
+    if ((m0[rr + NMAX] >> lane) & 1ull) { const int r = lds_find(Lt, me); if (r != me) Lt[me] = r; }
+  }
+  __syncthreads();
+  STAMP(1)
+  // ---- phase B: the rest of the up-left window --------------------------------------------------------------------------
+  const uint32_t kmask = (2u << n) - 1u;              // n + 1 low bits
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j;
@@ -229,128 +272,198 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
       const int qg = rr + NMAX - dv;                 // grid row of the window row
       const uint64_t q0 = m0[qg], qL = mL[qg];
       if ((q0 | qL) == 0) continue;                  // wave-uniform
+      // bit i of nb = pixel (lane - n + i) of the window row is dynamic  (i = n - k)
+      uint32_t nb;
+      if (lane >= n) nb = (uint32_t)(q0 >> (lane - n));
+      else nb = (uint32_t)((q0 << (n - lane)) | (qL >> (64 - (n - lane))));
+      nb = dyn ? (nb & kmask) : 0u;
+      if (dv == 0) nb &= ~(1u << n);                 // k == 0 is p itself
+      if (__ballot(nb != 0) == 0) continue;          // wave-uniform
       const int base = qg * PW + NMAX + lane;
-      float zq[NMAX + 1];
-      int lq[NMAX + 1];
-#pragma unroll
-      for (int k = 0; k <= NMAX; k++) { zq[k] = zt[base - k]; lq[k] = ld_relaxed(&Lt[base - k]); }
 #pragma unroll
       for (int k = 0; k <= NMAX; k++) {
-        if (dv == 0 && k == 0) continue;
-        const int qc = lane - k;
-        const bool bit = (qc >= 0) ? ((q0 >> qc) & 1ull) : ((qL >> (64 + qc)) & 1ull);
-        // (0,-1) inside the wave is the run link of phase A; across the tile edge (lane 0) it is an ordinary edge
-        const bool runlink = (dv == 0 && k == 1 && qc >= 0);
-        const bool valid = dyn && k <= n && bit && !runlink && !(fabsf(zp - zq[k]) > th);   // depthDiff gate (:194); NaN links
+        if (k > n || (dv == 0 && k == 0)) continue;  // wave-uniform
+        const bool bit = (nb >> (n - k)) & 1u;
+        // already linked: (0,-1) inside the wave is the run link of phase A1, (-1,0) the vertical link of phase A2
+        const bool pre = (dv == 0 && k == 1 && lane > 0) || (dv == 1 && k == 0);
+        const bool valid = bit && !pre && !(fabsf(zp - zt[base - k]) > th);   // depthDiff gate (:194); NaN links
         up = up || valid;
-        if (!(c.debug & 1)) wave_unite_lds(Lt, valid && lq[k] != cur && lq[k] != last, cur, last, lq[k], lane);
+        if (!(c.debug & 1)) {
+          bool need = false;
+          int lab = 0;
+          if (valid) { lab = ld_relaxed(&Lt[base - k]); need = lab != cur && lab != last; }
+          if (__ballot(need)) wave_unite_lds(Lt, need, cur, last, lab, lane);
+        }
       }
     }
+    STAMP(3)
     upr[j] = up;
   }
   __syncthreads();
-  // ---- phase C: publish -----------------------------------------------------------------------------------------------
-  int rootg[RPW];
+  STAMP(4)
+  // ---- phase C: publish ----------------------------------------------------------------------------------------------
+  // interior pixels point at their tile root (plain stores: nobody else writes these entries in this kernel), tile roots
+  // get an empty statistics record and a bit in the root plane
+  int rootg[RPW], rootc[RPW];
+  uint64_t rootbits[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, gy = y0 + rr;
     const bool dyn = (m0[rr + NMAX] >> lane) & 1ull;
-    int rg = -1;
+    int rg = -1, rc = -1;
     bool isroot = false;
     if (dyn) {
       const int me = (rr + NMAX) * PW + NMAX + lane;
       const int r = lds_find(Lt, me);                // interior by construction
       const int rgr = r / PW, rgc = r - rgr * PW;
       rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
-      const int gp = gy * c.W + x0 + lane;
+      rc = r;
+      a.parent[fN + (size_t)gy * c.W + x0 + lane] = rg;
       isroot = (r == me);
-      if (isroot) {
-        CompRec rec;
-        rec.size = 0; rec.key = kKeyNone;
-        rec.mn[0] = rec.mn[1] = rec.mn[2] = 0xffffffffu;
-        rec.mx[0] = rec.mx[1] = rec.mx[2] = 0u;
-        a.comps[fN + rg] = rec;
-      } else {
-        if (c.debug & 4) parent[gp] = rg;
-        else {
-          const int old = atomicMin(&parent[gp], rg);
-          if (old != gp) uf_unite(parent, old, rg);
-        }    // a neighbouring tile had already hooked p: keep both links
-      }
     }
-    rootg[j] = rg;
+    rootg[j] = rg; rootc[j] = rc;
     const uint64_t rb = __ballot(isroot);
+    rootbits[j] = rb;
     if (lane == 0 && gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + wi] = rb;
   }
-  // halo pixels that ended up in a tile component: unite them (they belong to other tiles) with the tile root in HBM
-  if (!(c.debug & 2)) {
+  STAMP(5)
+  // halo pixels that ended up in a tile component belong to other tiles, whose roots are not known yet: leave one link
+  // request (halo pixel, tile root) each for k_ccl_link
+  {
     const int topcells = n * (64 + n);               // n rows x (n + 64) columns above the tile
     const int total = topcells + TH * n;             // + TH rows x n columns left of it
-    for (int i = tid; i < total; i += 256) {
-      int gr, gc;
-      if (i < topcells) { gr = NMAX - n + i / (64 + n); gc = NMAX - n + i % (64 + n); }
-      else { const int t = i - topcells; gr = NMAX + t / n; gc = NMAX - n + t % n; }
-      const int cell = gr * PW + gc;
-      const int gx = x0 - NMAX + gc;
-      const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
-      if (gx < 0 || !((mw >> (gx & 63)) & 1ull)) continue;
-      const int hid = cell | kHaloBit;
-      const int r = lds_find(Lt, hid);
-      if (r == hid) continue;                         // not linked into the tile
-      const int rgr = r / PW, rgc = r - rgr * PW;
-      const int rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
-      const int hg = (y0 - NMAX + gr) * c.W + gx;
-      uf_unite(parent, hg, rg);
+    uint2 *req = a.requests + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * a.req_cap;
+    for (int i0 = 0; i0 < total; i0 += 256) {
+      const int i = i0 + tid;
+      bool linked = false;
+      int hg = 0, rg = 0;
+      if (i < total) {
+        int gr, gc;
+        if (i < topcells) { gr = NMAX - n + i / (64 + n); gc = NMAX - n + i % (64 + n); }
+        else { const int t = i - topcells; gr = NMAX + t / n; gc = NMAX - n + t % n; }
+        const int gx = x0 - NMAX + gc;
+        const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
+        if (gx >= 0 && ((mw >> (gx & 63)) & 1ull)) {
+          const int hid = (gr * PW + gc) | kHaloBit;
+          const int r = lds_find(Lt, hid);
+          if (r != hid) {                              // linked into a tile component
+            const int rgr = r / PW, rgc = r - rgr * PW;
+            rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
+            hg = (y0 - NMAX + gr) * c.W + gx;
+            linked = true;
+          }
+        }
+      }
+      const uint64_t lb = __ballot(linked);
+      if (lb) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&s_nreq, __popcll((unsigned long long)lb));
+        base = __shfl(base, 0);
+        if (linked) req[base + __popcll((unsigned long long)(lb & ((1ull << lane) - 1ull)))] = make_uint2((uint32_t)hg, (uint32_t)rg);
+      }
     }
   }
-  __syncthreads();   // record initialisation has reached L2 before any wave's atomics on it
-  // ---- phase D: partial statistics of the tile's components ---------------------------------------------------------
+  STAMP(6)
+  __syncthreads();                                   // every find on Lt is done: root cells can be re-used as slot tags
+  // ---- phase D: partial statistics of the tile's components --------------------------------------------------------
+  // The tile owns its roots' records, so they are reduced in LDS slots and stored once — no global atomics.  Roots beyond
+  // kSlots (very fragmented tiles) fall back to initialise-then-atomics on the global record.
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    const bool isroot = (rootbits[j] >> lane) & 1ull;
+    if (isroot) {
+      const int slot = atomicAdd(&s_nslots, 1);
+      CompRec rec;
+      rec.size = 0; rec.key = kKeyNone;
+      rec.mn[0] = rec.mn[1] = rec.mn[2] = 0xffffffffu;
+      rec.mx[0] = rec.mx[1] = rec.mx[2] = 0u;
+      if (slot < kSlots) { srec[slot] = rec; sroot[slot] = rootg[j]; Lt[rootc[j]] = -(slot + 1); }
+      else a.comps[fN + rootg[j]] = rec;
+    }
+  }
+  __syncthreads();   // slot tags visible; overflow records have reached L2 before any wave's atomics on them
+  STAMP(7)
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, gy = y0 + rr;
     if (m0[rr + NMAX] == 0 || (c.debug & 8)) continue;                // wave-uniform
     const int rg = rootg[j];
     uint32_t ox = 0, oy = 0, oz = 0, key = (uint32_t)kKeyNone;
+    int slot = -1, over = -1;
     if (rg >= 0) {
       const size_t gp = (size_t)gy * c.W + x0 + lane;
       ox = f2ord(a.x[fN + gp]); oy = f2ord(a.y[fN + gp]); oz = f2ord(zt[(rr + NMAX) * PW + NMAX + lane]);
       if (upr[j]) key = (uint32_t)gp;
+      const int tag = Lt[rootc[j]];
+      if (tag < 0) slot = -tag - 1; else over = rg;
     }
-    wave_accumulate(a.comps + fN, rg, key, ox, oy, oz, lane);
+    wave_accumulate(srec, slot, key, ox, oy, oz, lane);
+    if (__ballot(over >= 0)) wave_accumulate(a.comps + fN, over, key, ox, oy, oz, lane);
+  }
+  __syncthreads();
+  {
+    const int ns = min(s_nslots, kSlots);
+    if (tid < ns) a.comps[fN + sroot[tid]] = srec[tid];
+  }
+  STAMP(8)
+#undef STAMP
+  if (tid == 0) { hdr[0] = 1; hdr[1] = s_nreq; }   // s_nreq is final: the barrier after the request loop has passed
+}
+
+// Cross-tile links.  One workgroup per tile walks the tile's requests (halo pixel h, tile root r): h's own tile has
+// published parent[h] = its tile root by now, so the union is between two tile roots — all parent writes here are
+// atomicMin hooks on root entries.  Consecutive requests usually name the same pair; only the first lane of a run acts.
+template <int TH>
+__global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a) {
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x, f = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+  const size_t tidx = (size_t)f * gridDim.y * gridDim.x + tile;
+  const int *hdr = a.tilehdr + tidx * 2;
+  const int nreq = hdr[1];
+  if (hdr[0] == 0 || nreq == 0) return;
+  const size_t N = (size_t)c.W * c.H;
+  int *parent = a.parent + (size_t)f * N;
+  const uint2 *req = a.requests + tidx * a.req_cap;
+  for (int i0 = 0; i0 < nreq; i0 += 256) {
+    const int i = i0 + tid;
+    int ra = -1, rb = -1;
+    if (i < nreq) { const uint2 q = req[i]; ra = parent[q.x]; rb = (int)q.y; }
+    const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
+    if (ra >= 0 && !(lane > 0 && pa == ra && pb == rb)) uf_unite(parent, ra, rb);
   }
 }
 
-// Root per pixel (labels plane holds the root's pixel index, -1 for non-dynamic pixels); tile-local records are
-// folded into their root's record; roots append themselves to the frame's root list.
-__global__ __launch_bounds__(256) void k_ccl_flatten(DevCam c, ClArgs a) {
-  const int lane = threadIdx.x, wi = blockIdx.x, x = wi * 64 + lane, y = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
-  if (y >= c.H || x >= c.W) return;
+// Root-level flatten.  One workgroup per tile: every tile root finds its final root, remembers it (path compression,
+// so pixels are two hops from their final root), and folds its partial record into the final root's record; final
+// roots list themselves for k_select.
+template <int TH>
+__global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a) {
+  const int wi = blockIdx.x, f = blockIdx.z, lane = threadIdx.x, w = threadIdx.y;
+  const size_t tidx = (size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi;
+  if (a.tilehdr[tidx * 2] == 0) return;
   const size_t N = (size_t)c.W * c.H;
-  const size_t wofs = ((size_t)f * c.H + y) * c.mask_words + wi;
-  const uint64_t mword = a.mask[wofs];
-  const int p = y * c.W + x;
-  int out = -1;
-  if ((mword >> lane) & 1ull) {
-    const int *parent = a.parent + (size_t)f * N;
+  int *parent = a.parent + (size_t)f * N;
+  CompRec *recs = a.comps + (size_t)f * N;
+  for (int j = w; j < TH; j += 4) {
+    const int y = blockIdx.y * TH + j;
+    if (y >= c.H) break;
+    const uint64_t rb = a.lroot[((size_t)f * c.H + y) * c.mask_words + wi];
+    if (!((rb >> lane) & 1ull)) continue;
+    const int p = y * c.W + wi * 64 + lane;
     const int r = uf_find(parent, p);
-    out = r;
-    if ((a.lroot[wofs] >> lane) & 1ull) {
-      CompRec *recs = a.comps + (size_t)f * N;
-      if (r == p) {
-        const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
-        a.rootlist[(size_t)f * N + slot] = p;
-      } else {
-        const CompRec mine = recs[p];
-        CompRec *t = recs + r;
-        atomicAdd(&t->size, mine.size);
-        if (mine.key != kKeyNone) atomicMin(&t->key, mine.key);
-        atomicMin(&t->mn[0], mine.mn[0]); atomicMax(&t->mx[0], mine.mx[0]);
-        atomicMin(&t->mn[1], mine.mn[1]); atomicMax(&t->mx[1], mine.mx[1]);
-        atomicMin(&t->mn[2], mine.mn[2]); atomicMax(&t->mx[2], mine.mx[2]);
-      }
+    if (r == p) {
+      const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
+      a.rootlist[(size_t)f * N + slot] = p;
+    } else {
+      parent[p] = r;   // r is final: no union runs after k_ccl_link
+      const CompRec mine = recs[p];
+      CompRec *t = recs + r;
+      atomicAdd(&t->size, mine.size);
+      if (mine.key != kKeyNone) atomicMin(&t->key, mine.key);
+      atomicMin(&t->mn[0], mine.mn[0]); atomicMax(&t->mx[0], mine.mx[0]);
+      atomicMin(&t->mn[1], mine.mn[1]); atomicMax(&t->mx[1], mine.mx[1]);
+      atomicMin(&t->mn[2], mine.mn[2]); atomicMax(&t->mx[2], mine.mx[2]);
     }
   }
-  a.labels[(size_t)f * N + p] = out;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -417,40 +530,48 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
   }
 }
 
-// Final labels + member compaction: labels[p] = new label (or -1); members of surviving clusters append
-// (||v|| bits, pixel) to their cluster's segment, one cursor atomic per (wave, cluster).
-__global__ __launch_bounds__(256) void k_relabel(DevCam c, ClArgs a) {
-  const int lane = threadIdx.x, wi = blockIdx.x, x = wi * 64 + lane, y = blockIdx.y * 4 + threadIdx.y, f = blockIdx.z;
-  if (y >= c.H) return;
+// Final labels + member compaction, one workgroup per tile: labels[p] = new label of p's component or -1 (the whole
+// plane is written here, 4 B/px); members of surviving clusters append (||v|| bits, pixel) to their cluster's segment,
+// one cursor atomic per (wave row, cluster).
+template <int TH>
+__global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
+  const int wi = blockIdx.x, f = blockIdx.z, lane = threadIdx.x, w = threadIdx.y;
+  const size_t tidx = (size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi;
+  const bool active = a.tilehdr[tidx * 2] != 0;
   const size_t N = (size_t)c.W * c.H;
-  const uint64_t mword = a.mask[((size_t)f * c.H + y) * c.mask_words + wi];
-  if (mword == 0) return;                                 // labels already hold -1 there (k_ccl_flatten)
-  int *lab = a.labels + (size_t)f * N;
-  const int p = y * c.W + x;
-  const bool dyn = (mword >> lane) & 1ull;
-  int nl = -1;
-  uint32_t nb = 0;
-  if (dyn) {
-    const int r = lab[p];
-    nl = a.comps[(size_t)f * N + r].key;                  // new label of the root's component, or -1
-    lab[p] = nl;
-    if (nl >= 0) nb = __float_as_uint(norm3_f32(a.vx[(size_t)f * N + p], a.vy[(size_t)f * N + p], a.vz[(size_t)f * N + p]));
-  }
-  uint64_t todo = __ballot(nl >= 0);
-  while (todo) {
-    const int leader = __ffsll((unsigned long long)todo) - 1;
-    const int l = __shfl(nl, leader);
-    const bool mine = (nl == l);
-    const uint64_t grp = __ballot(mine);
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&a.cursors[(size_t)f * a.max_objects + l], __popcll((unsigned long long)grp));
-    base = __shfl(base, leader);
-    if (mine) {
-      const int rank = __popcll((unsigned long long)(grp & ((1ull << lane) - 1ull)));
-      const int off = a.clusters[(size_t)f * a.max_objects + l].offset;
-      a.members[(size_t)f * N + off + base + rank] = make_uint2(nb, (uint32_t)p);
+  const size_t fN = (size_t)f * N;
+  const int x = wi * 64 + lane;
+  for (int j = w; j < TH; j += 4) {
+    const int y = blockIdx.y * TH + j;
+    if (y >= c.H) break;
+    const int p = y * c.W + x;
+    int nl = -1;
+    uint32_t nb = 0;
+    uint64_t mword = 0;
+    if (active) mword = a.mask[((size_t)f * c.H + y) * c.mask_words + wi];
+    if ((mword >> lane) & 1ull) {
+      const int lr = a.parent[fN + p];                    // tile root ...
+      const int r = a.parent[fN + lr];                    // ... whose entry names the final root (k_ccl_merge)
+      nl = a.comps[fN + r].key;                           // new label of the component, or -1
+      if (nl >= 0) nb = __float_as_uint(norm3_f32(a.vx[fN + p], a.vy[fN + p], a.vz[fN + p]));
     }
-    todo &= ~grp;
+    if (x < c.W) a.labels[fN + p] = nl;
+    uint64_t todo = __ballot(nl >= 0);
+    while (todo) {
+      const int leader = __ffsll((unsigned long long)todo) - 1;
+      const int l = __shfl(nl, leader);
+      const bool mine = (nl == l);
+      const uint64_t grp = __ballot(mine);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&a.cursors[(size_t)f * a.max_objects + l], __popcll((unsigned long long)grp));
+      base = __shfl(base, leader);
+      if (mine) {
+        const int rank = __popcll((unsigned long long)(grp & ((1ull << lane) - 1ull)));
+        const int off = a.clusters[(size_t)f * a.max_objects + l].offset;
+        a.members[fN + off + base + rank] = make_uint2(nb, (uint32_t)p);
+      }
+      todo &= ~grp;
+    }
   }
 }
 
@@ -637,21 +758,24 @@ constexpr int kTileH = 16;
 
 void launch_ccl(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   dim3 block(64, 4, 1);
-  dim3 grid(c.mask_words, (c.H + 3) / 4, frames);
   dim3 tgrid(c.mask_words, (c.H + kTileH - 1) / kTileH, frames);
-  hipLaunchKernelGGL(k_ccl_init, grid, block, 0, s, c, a);
   if (c.n <= 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4>), tgrid, block, 0, s, c, a);
   else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8>), tgrid, block, 0, s, c, a);
   else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16>), tgrid, block, 0, s, c, a);
-  hipLaunchKernelGGL(k_ccl_flatten, grid, block, 0, s, c, a);
+  hipLaunchKernelGGL(k_ccl_link<kTileH>, tgrid, dim3(256), 0, s, c, a);
+  hipLaunchKernelGGL(k_ccl_merge<kTileH>, tgrid, block, 0, s, c, a);
 }
 
 void launch_objects(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  dim3 block(64, 4, 1), grid(c.mask_words, (c.H + 3) / 4, frames);
+  dim3 block(64, 4, 1);
+  dim3 tgrid(c.mask_words, (c.H + kTileH - 1) / kTileH, frames);
   // the second ClusterInfo array (rank scratch) lives right behind the first one
   ClusterInfo *tmp = a.clusters + (size_t)frames * a.max_objects;
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
-  hipLaunchKernelGGL(k_relabel, grid, block, 0, s, c, a);
+  hipLaunchKernelGGL(k_final<kTileH>, tgrid, block, 0, s, c, a);
   hipLaunchKernelGGL(k_median, dim3(16, frames), dim3(kMedThreads), 0, s, c, a);
   hipLaunchKernelGGL(k_finalize, dim3((frames + 63) / 64), dim3(64), 0, s, c, a, frames);
 }
+
+int ccl_tile_rows() { return kTileH; }
+int ccl_request_capacity(int n) { return n * (64 + n) + kTileH * n; }

@@ -29,6 +29,10 @@ struct ClArgs {
   int32_t *n_objects;         // [F]
   int32_t *n_clusters;        // [F] or null
   int32_t max_objects;
+  uint2 *requests;            // [F][tiles][req_cap] cross-tile link requests (halo pixel, tile root)
+  int32_t *tilehdr;           // [F][tiles][2]: active flag, number of requests
+  int32_t req_cap;
+  unsigned long long *dbg;    // [32] cycle counters, only touched when DevCam.debug & 128
 };
 
 void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s);
@@ -42,3 +46,5 @@ void launch_unpack(size_t n, const void *aos, float *x, float *y, float *z, floa
 void launch_ccl(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 // stats + size filter/order + relabel/member compaction + median velocity + object emission (MOD_STAGE_OBJECTS)
 void launch_objects(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+int ccl_tile_rows();                 // tile height of k_ccl_tile
+int ccl_request_capacity(int n);     // link requests one tile can emit at neighbor_distance n

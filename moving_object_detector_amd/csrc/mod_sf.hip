@@ -26,6 +26,10 @@ struct Buffers {
   ClusterInfo *clusters = nullptr;          // 2 x [maxF][max_objects]
   uint2 *members = nullptr;
   int32_t *cursors = nullptr;
+  unsigned long long *dbg = nullptr;
+  uint2 *requests = nullptr;
+  int32_t *tilehdr = nullptr;
+  size_t req_alloc = 0;                     // entries currently allocated for `requests`
   // one-frame staging for the *_host entry points (allocated on first use)
   float *h_dnow = nullptr, *h_dprev = nullptr, *h_flow = nullptr, *h_planes = nullptr;
   void *h_aos = nullptr;
@@ -208,7 +212,8 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.members;
   a.labels = out->labels; a.comps = c->b.comps; a.counters = c->b.counters; a.clusters = c->b.clusters;
   a.members = c->b.members; a.cursors = c->b.cursors; a.objects = out->objects; a.n_objects = out->n_objects;
-  a.n_clusters = out->n_clusters; a.max_objects = c->max_objects;
+  a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
+  a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
   {
     StageTimer t(c, MOD_STAGE_CCL);
     if (!mask_ready) launch_dynamic_mask(c->dc, frames, pl->vx, pl->vy, pl->vz, (uint64_t *)mask, c->stream);
@@ -261,6 +266,12 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   ok &= dalloc(&c->b.clusters, (size_t)2 * F * c->max_objects) == hipSuccess;
   ok &= dalloc(&c->b.members, (size_t)F * N) == hipSuccess;
   ok &= dalloc(&c->b.cursors, (size_t)F * c->max_objects) == hipSuccess;
+  {
+    const size_t tiles = (size_t)c->max_mask_words * ((cfg->max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
+    ok &= dalloc(&c->b.tilehdr, (size_t)F * tiles * 2) == hipSuccess;
+  }
+  ok &= dalloc(&c->b.dbg, 32) == hipSuccess;
+  if (ok) ok &= hipMemset(c->b.dbg, 0, 32 * 8) == hipSuccess;
   for (int i = 0; i < kRing && ok; i++) {
     ok &= hipHostMalloc((void **)&c->pinned[i], sizeof(FrameConst) * F, hipHostMallocDefault) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->pinned_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -276,7 +287,7 @@ void mod_destroy(ModContext *c) {
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
   void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.comps, b.counters, b.clusters, b.members,
-                 b.cursors, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
+                 b.cursors, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
     if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
@@ -314,6 +325,17 @@ int mod_set_params(ModContext *c, const ModParams *p) {
   if (p->neighbor_distance < 1 || p->neighbor_distance > MOD_MAX_NEIGHBOR_DISTANCE)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "neighbor_distance must be in 1..16");
   if (p->cluster_size < 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster_size must be >= 1");
+  {   // link-request scratch grows with neighbor_distance
+    const size_t tiles = (size_t)c->max_mask_words * ((c->cfg.max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
+    const size_t need = (size_t)c->cfg.max_frames * tiles * ccl_request_capacity(p->neighbor_distance);
+    if (need > c->b.req_alloc) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (c->b.requests) HIP_TRY(c, hipFree(c->b.requests));
+      c->b.requests = nullptr; c->b.req_alloc = 0;
+      HIP_TRY(c, dalloc(&c->b.requests, need));
+      c->b.req_alloc = need;
+    }
+  }
   c->prm = *p;
   c->has_prm = true;
   refresh_devcam(c);
@@ -501,6 +523,14 @@ int mod_memcpy_d2h(ModContext *c, void *h, const void *d, uint64_t bytes) {
   if (!c) return MOD_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MOD_OK;
+}
+
+int mod_debug_counters(ModContext *c, unsigned long long *out32) {
+  if (!c || !out32) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out32, c->b.dbg, 32 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemset(c->b.dbg, 0, 32 * 8));
   return MOD_OK;
 }
 
