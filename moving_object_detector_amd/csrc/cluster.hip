@@ -30,6 +30,10 @@ namespace {
 
 constexpr int kKeyNone = 0x7fffffff;
 
+// Workgroup barrier for phases that only exchange data through LDS: waits for this wave's LDS operations, not for its
+// outstanding global loads/stores (__syncthreads() drains vmcnt(0) and would serialise every HBM round trip).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------------------------------
 // Union-find helpers.  parent[i] <= i always; roots satisfy parent[r] == r; a larger root is hooked under a smaller
 // one with atomicMin, whose return value tells whether the node was still a root.  Reads are relaxed atomic loads so
@@ -200,21 +204,40 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   unsigned long long t0 = prof ? clock64() : 0, t1;
 #define STAMP(i) if (prof) { t1 = clock64(); if (lane == 0) { atomicAdd(&a.dbg[i], t1 - t0); atomicMax(&a.dbg[16 + i], t1 - t0); } t0 = t1; }
   // ---- phase A: masked depth + identity parents; grid row gr = image row y0 - NMAX + gr, 4 rows per step -----------
-  for (int gr = w; gr < PH; gr += 4) {
-    const uint64_t q0 = m0[gr], qL = mL[gr];          // zero for rows that are unused or outside the image
-    const size_t rowp = fN + (size_t)(y0 - NMAX + gr) * c.W + x0;
-    const int cell = gr * PW + NMAX + lane;
-    const bool d = (q0 >> lane) & 1ull;
-    zt[cell] = d ? a.z[rowp + lane] : 0.0f;
-    Lt[cell] = (gr >= NMAX) ? cell : (cell | kHaloBit);
-    if (lane < n) {                                   // left halo: column x0 - 1 - lane
-      const int hc = gr * PW + NMAX - 1 - lane;
-      const bool dl = (qL >> (63 - lane)) & 1ull;
-      zt[hc] = dl ? a.z[rowp - 1 - lane] : 0.0f;
-      Lt[hc] = hc | kHaloBit;
+  // All HBM reads of the kernel are issued here, unconditionally (clamped addresses, values of non-dynamic pixels are
+  // discarded): predicated loads would compile to one exec-masked branch + wait each, i.e. one round trip per row.
+  constexpr int AROWS = (PH + 3) / 4;
+  float xr[RPW], yr[RPW], zl[AROWS], zh[AROWS];
+  const int xc = min(x0 + lane, c.W - 1), xhc = max(x0 - 1 - lane, 0);
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    const size_t gp = fN + (size_t)min(y0 + r0 + j, c.H - 1) * c.W + xc;
+    xr[j] = a.x[gp];
+    yr[j] = a.y[gp];
+  }
+#pragma unroll
+  for (int i = 0; i < AROWS; i++) {
+    const int gy = min(max(y0 - NMAX + w + 4 * i, 0), c.H - 1);
+    const size_t rowp = fN + (size_t)gy * c.W;
+    zl[i] = a.z[rowp + xc];
+    zh[i] = a.z[rowp + xhc];                          // left halo: column x0 - 1 - lane (lanes < n)
+  }
+#pragma unroll
+  for (int i = 0; i < AROWS; i++) {
+    const int gr = w + 4 * i;
+    if (gr < PH) {
+      const uint64_t q0 = m0[gr], qL = mL[gr];        // zero for rows that are unused or outside the image
+      const int cell = gr * PW + NMAX + lane;
+      zt[cell] = ((q0 >> lane) & 1ull) ? zl[i] : 0.0f;
+      Lt[cell] = (gr >= NMAX) ? cell : (cell | kHaloBit);
+      if (lane < n) {
+        const int hc = gr * PW + NMAX - 1 - lane;
+        zt[hc] = ((qL >> (63 - lane)) & 1ull) ? zh[i] : 0.0f;
+        Lt[hc] = hc | kHaloBit;
+      }
     }
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(0)
   // ---- phase A1: horizontal runs of the wave's rows by ballot (no atomics) ---------------------------------------------
   bool upr[RPW];
@@ -234,7 +257,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     }
     upr[j] = cl;
   }
-  __syncthreads();
+  lds_barrier();
   // ---- phase A2: vertical pre-link (the pixel straight above), one union per distinct (run, run-above) pair -----------
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
@@ -247,14 +270,14 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     wave_unite_lds(Lt, link, cur, last, ld_relaxed(&Lt[me - PW]), lane);
     upr[j] = upr[j] || link;
   }
-  __syncthreads();
+  lds_barrier();
   // ---- phase A3: flatten, so that phase B can compare labels directly ----------------------------------------------------
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
     if ((m0[rr + NMAX] >> lane) & 1ull) { const int r = lds_find(Lt, me); if (r != me) Lt[me] = r; }
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(1)
   // ---- phase B: the rest of the up-left window --------------------------------------------------------------------------
   const uint32_t kmask = (2u << n) - 1u;              // n + 1 low bits
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     STAMP(3)
     upr[j] = up;
   }
-  __syncthreads();
+  lds_barrier();
   STAMP(4)
   // ---- phase C: publish ----------------------------------------------------------------------------------------------
   // interior pixels point at their tile root (plain stores: nobody else writes these entries in this kernel), tile roots
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     }
   }
   STAMP(6)
-  __syncthreads();                                   // every find on Lt is done: root cells can be re-used as slot tags
+  lds_barrier();                                     // every find on Lt is done: root cells can be re-used as slot tags
   // ---- phase D: partial statistics of the tile's components --------------------------------------------------------
   // The tile owns its roots' records, so they are reduced in LDS slots and stored once — no global atomics.  Roots beyond
   // kSlots (very fragmented tiles) fall back to initialise-then-atomics on the global record.
@@ -381,7 +404,8 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
       else a.comps[fN + rootg[j]] = rec;
     }
   }
-  __syncthreads();   // slot tags visible; overflow records have reached L2 before any wave's atomics on them
+  lds_barrier();     // slot tags visible
+  if (s_nslots > kSlots) __syncthreads();   // overflow records must have reached L2 before any wave's atomics on them
   STAMP(7)
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
@@ -392,7 +416,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     int slot = -1, over = -1;
     if (rg >= 0) {
       const size_t gp = (size_t)gy * c.W + x0 + lane;
-      ox = f2ord(a.x[fN + gp]); oy = f2ord(a.y[fN + gp]); oz = f2ord(zt[(rr + NMAX) * PW + NMAX + lane]);
+      ox = f2ord(xr[j]); oy = f2ord(yr[j]); oz = f2ord(zt[(rr + NMAX) * PW + NMAX + lane]);
       if (upr[j]) key = (uint32_t)gp;
       const int tag = Lt[rootc[j]];
       if (tag < 0) slot = -tag - 1; else over = rg;
@@ -400,7 +424,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     wave_accumulate(srec, slot, key, ox, oy, oz, lane);
     if (__ballot(over >= 0)) wave_accumulate(a.comps + fN, over, key, ox, oy, oz, lane);
   }
-  __syncthreads();
+  lds_barrier();
   {
     const int ns = min(s_nslots, kSlots);
     if (tid < ns) a.comps[fN + sroot[tid]] = srec[tid];
