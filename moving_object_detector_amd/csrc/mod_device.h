@@ -63,8 +63,13 @@ __device__ __forceinline__ float ord2f(uint32_t o) {
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
-// Eigen Vector3f::norm(): sqrt(x^2 + (y^2 + z^2)), every step rounded to F32 (no contraction).
+// Eigen Vector3f::norm(): sqrt(x^2 + (y^2 + z^2)), every step rounded to F32.
+// Plain operators + sqrtf on purpose: the build uses -ffp-contract=off and -fhip-fp32-correctly-rounded-divide-sqrt, whereas
+// HIP's __fsqrt_rn() lowers to the *native* (approximate) square root unless OCML_BASIC_ROUNDED_OPERATIONS is defined.
+#pragma clang fp contract(off)
 __device__ __forceinline__ float norm3_f32(float vx, float vy, float vz) {
-  float xx = __fmul_rn(vx, vx), yy = __fmul_rn(vy, vy), zz = __fmul_rn(vz, vz);
-  return __fsqrt_rn(__fadd_rn(xx, __fadd_rn(yy, zz)));
+  const float xx = vx * vx, yy = vy * vy, zz = vz * vz;
+  const float s = yy + zz;
+  const float t = xx + s;
+  return sqrtf(t);
 }

@@ -526,6 +526,16 @@ int mod_memcpy_d2h(ModContext *c, void *h, const void *d, uint64_t bytes) {
   return MOD_OK;
 }
 
+// diagnostic: copy an internal buffer to the host (0 members, 1 clusters, 2 counters, 3 cursors)
+int mod_debug_read(ModContext *c, int which, void *dst, unsigned long long bytes) {
+  if (!c || !dst) return MOD_ERR_INVALID_ARGUMENT;
+  const void *src = which == 0 ? (const void *)c->b.members : which == 1 ? (const void *)c->b.clusters
+                  : which == 2 ? (const void *)c->b.counters : (const void *)c->b.cursors;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return MOD_OK;
+}
+
 int mod_debug_counters(ModContext *c, unsigned long long *out32) {
   if (!c || !out32) return MOD_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

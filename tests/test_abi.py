@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library loads, exports every symbol include/mod_sf.h declares, mirrors its struct layouts, and fails
+loudly — never falls back — when there is no device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "mod_sf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:int|void|const char \*)\s*\**\s*(mod_[a-z0-9_]+)\s*\(", src, flags=re.M)
+    return [n for n in names if n != "mod_mask_words"]
+
+
+def test_header_and_binding_list_agree():
+    from moving_object_detector_amd import capi
+    assert sorted(declared_functions()) == sorted(capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    from moving_object_detector_amd import capi
+    lib = capi.load()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert lib.mod_abi_version() == 1
+
+
+def test_struct_layouts():
+    from moving_object_detector_amd import capi
+    assert C.sizeof(capi.ModObject) == 112
+    assert C.sizeof(capi.ModCamera) == 72 and C.sizeof(capi.ModParams) == 32 and C.sizeof(capi.ModTransform) == 56
+    assert capi.ModObject.center.offset == 8 and capi.ModObject.velocity.offset == 64 and capi.ModObject.bounding_box.offset == 88
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    import torch
+    from moving_object_detector_amd import capi
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = capi.load()
+    cfg = capi.ModConfig(0, 64, 48, 1, 0, 0, None)
+    h = C.c_void_p()
+    assert lib.mod_create(C.byref(cfg), C.byref(h)) == capi.MOD_ERR_NO_DEVICE
+    assert not h.value
+    from moving_object_detector_amd.pipeline import Context
+    with pytest.raises(RuntimeError):
+        Context(64, 48)
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    from moving_object_detector_amd import capi
+    monkeypatch.setattr(capi, "_lib", None)
+    monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "libmod_sf.so"))
+    with pytest.raises(ImportError):
+        capi.load()

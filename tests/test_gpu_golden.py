@@ -1,0 +1,111 @@
+"""GPU: the HIP path through the C ABI against the committed golden fixtures — device entry points, the host-pointer
+entry points a ROS node would call, skip / error codes."""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_golden import GOLD, golden_objects, load_case
+from util import PLANES, bits_equal, compare_objects, first_mismatch
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _ctx(cam, prm, frames=1):
+    from moving_object_detector_amd.pipeline import Context
+    ctx = Context(cam.width, cam.height, max_frames=frames)
+    ctx.set_camera(cam)
+    ctx.set_params(prm)
+    return ctx
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_device_path_matches_golden(path):
+    g, cam, prm = load_case(path)
+    ctx = _ctx(cam, prm)
+    ws = ctx.workspace(1, aos=True, extras=True)
+    dev = ctx.device
+    b = ctx.make_batch(torch.from_numpy(g["d_now"][None]).to(dev), torch.from_numpy(g["d_prev"][None]).to(dev),
+                       torch.from_numpy(g["flow"][None]).to(dev), g["t"][None], g["q"][None], [float(g["dt"])])
+    assert ctx.process(b, ws) == 0
+    ctx.synchronize()
+    for i, k in enumerate(PLANES):
+        got = ws["planes"][i, 0].cpu().numpy()
+        assert bits_equal(got, g[k]), (k, first_mismatch(got, g[k]))
+    assert bits_equal(ws["static_flow"][0].cpu().numpy(), g["static_flow"])
+    assert np.array_equal(ws["labels"][0].cpu().numpy(), g["labels"])
+    assert int(ws["n_clusters"][0]) == int(np.asarray(g["K"]).item())
+    compare_objects(ctx.objects_to_host(ws)[0], golden_objects(g), strict_velocity=False)
+    ctx.close()
+
+
+@pytest.mark.parametrize("path", GOLD[:3], ids=[os.path.basename(p) for p in GOLD[:3]])
+def test_host_entry_points_match_golden(path):
+    """mod_process_frame_host + mod_cluster_cloud_host: what a ROS node with host-side messages calls."""
+    from moving_object_detector_amd import capi
+    from moving_object_detector_amd.pipeline import OBJECT_DTYPE
+    g, cam, prm = load_case(path)
+    g = {k: np.ascontiguousarray(g[k]) for k in g.files}     # NpzFile hands out temporaries: keep the arrays alive
+    ctx = _ctx(cam, prm)
+    H, W = g["d_now"].shape
+    cloud = np.zeros((H, W, 8), np.float32)
+    labels = np.zeros((H, W), np.int32)
+    objs = np.zeros(64, OBJECT_DTYPE)
+    n = C.c_int32(-1)
+    tf = capi.transforms_array([g["t"]], [g["q"]])
+    rc = ctx.lib.mod_process_frame_host(ctx.h, g["d_now"].ctypes.data, g["d_prev"].ctypes.data, g["flow"].ctypes.data, tf,
+                                        float(g["dt"]), cloud.ctypes.data, labels.ctypes.data, objs.ctypes.data, 64, C.byref(n))
+    assert rc == 0
+    for j, k in zip((0, 1, 2, 4, 5, 6), PLANES):
+        assert bits_equal(cloud[..., j], g[k]), k
+    assert np.array_equal(labels, g["labels"]) and n.value == int(np.asarray(g["n_objects"]).item())
+    compare_objects(objs[: n.value], golden_objects(g), strict_velocity=False)
+    # clusterer alone on the PointCloud2 payload (ClustererNodelet::dataCB)
+    labels2 = np.zeros((H, W), np.int32)
+    n2 = C.c_int32(-1)
+    rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W, H, 32, 32 * W, labels2.ctypes.data, objs.ctypes.data, 64, C.byref(n2))
+    assert rc == 0 and np.array_equal(labels2, g["labels"]) and n2.value == n.value
+    # a cloud of the wrong size is an error, not a silent skip
+    rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W - 1, H, 32, 32 * W, labels2.ctypes.data, objs.ctypes.data, 64, C.byref(n2))
+    assert rc == capi.MOD_ERR_INVALID_ARGUMENT and b"cloud size" in ctx.lib.mod_last_error(ctx.h)
+    ctx.close()
+
+
+def test_missing_inputs_return_skip_codes():
+    """construct() guards (scene_flow_constructor.cpp:104,110,122,127,133): a missing input is a skip, not an error."""
+    from moving_object_detector_amd import capi
+    g, cam, prm = load_case(GOLD[0])
+    g = {k: np.ascontiguousarray(g[k]) for k in g.files}
+    ctx = _ctx(cam, prm)
+    n = C.c_int32(-1)
+    tf = capi.transforms_array([g["t"]], [g["q"]])
+    a = (g["d_now"].ctypes.data, g["d_prev"].ctypes.data, g["flow"].ctypes.data)
+    call = lambda dn, dp, fl, t: ctx.lib.mod_process_frame_host(ctx.h, dn, dp, fl, t, 0.1, None, None, None, 0, C.byref(n))
+    assert call(a[0], a[1], None, tf) == capi.MOD_SKIP_NO_FLOW and n.value == 0
+    assert call(a[0], None, a[2], tf) == capi.MOD_SKIP_NO_DISPARITY_PREV
+    assert call(a[0], a[1], a[2], None) == capi.MOD_SKIP_NO_TRANSFORM
+    assert call(None, a[1], a[2], tf) == capi.MOD_SKIP_NO_DISPARITY_NOW
+    assert call(a[0], a[1], a[2], tf) == 0
+    ctx.close()
+
+
+def test_configuration_errors():
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+    ctx = Context(64, 48, max_frames=1)
+    ws = ctx.workspace(1)
+    z = torch.zeros((1, 48, 64), device=ctx.device)
+    b = ctx.make_batch(z, z, torch.zeros((1, 48, 64, 2), device=ctx.device), [[0, 0, 0]], [[0, 0, 0, 1]], [0.1])
+    with pytest.raises(capi.ModError) as e:
+        ctx.process(b, ws)                                 # camera / params not set
+    assert e.value.code == capi.MOD_ERR_NOT_CONFIGURED
+    with pytest.raises(capi.ModError):
+        ctx.set_camera(synth.make_camera(128, 48))        # larger than the context was created for
+    with pytest.raises(capi.ModError):
+        ctx.set_params(synth.Params(neighbor_distance=17))
+    with pytest.raises(capi.ModError):
+        ctx.set_params(synth.Params(cluster_size=0))
+    ctx.close()

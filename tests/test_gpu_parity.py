@@ -103,3 +103,35 @@ def test_unfused_equals_fused(oracle):
     assert np.array_equal(a["mask"], b["mask"])
     for k in PLANES:
         assert bits_equal(a[k], b[k])
+
+
+def test_dynamic_mask_is_exact_at_the_threshold():
+    """calculateDynamicMap compares (double)||v||_f32 >= dynamic_speed; ||v|| needs an IEEE square root (HIP's __fsqrt_rn
+    is the *native* approximation) and the F64 threshold is folded into an F32 one on the host.  Thousands of norms sit
+    within a few ulps of the threshold here, including exact ties."""
+    import ctypes as C
+    from moving_object_detector_amd import synth
+    from moving_object_detector_amd.pipeline import Context
+    from oracle import numpy_ref
+    W, H = 512, 64
+    rng = np.random.default_rng(77)
+    d = rng.normal(size=(3, H, W))
+    d /= np.linalg.norm(d, axis=0)
+    scale = 0.7 * (1.0 + rng.integers(-40, 41, size=(H, W)) * 2.0 ** -23)      # norms within ~40 ulp of 0.7
+    v = (d * scale).astype(np.float32)
+    v[:, 0, :8] = np.nan
+    v[:, 1, :8] = 0.0
+    for th in (float(numpy_ref.norm3(v[0], v[1], v[2])[5, 5]), 0.7, float(np.float32(0.7)), np.nextafter(0.7, 1.0)):
+        prm = synth.Params(dynamic_speed=th)
+        ctx = Context(W, H, max_frames=1)
+        ctx.set_camera(synth.make_camera(W, H))
+        ctx.set_params(prm)
+        t = [torch.from_numpy(v[i][None].copy()).to(ctx.device) for i in range(3)]
+        mask = torch.zeros((1, H, W // 64), dtype=torch.int64, device=ctx.device)
+        assert ctx.lib.mod_dynamic_mask_dev(ctx.h, 1, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), mask.data_ptr()) == 0
+        ctx.synchronize()
+        bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[0].astype(bool)
+        want = numpy_ref.dynamic_mask(prm, v[0], v[1], v[2])
+        assert np.array_equal(bits, want), (th, int((bits != want).sum()))
+        assert 0.2 < want.mean() < 0.8
+        ctx.close()
