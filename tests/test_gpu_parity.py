@@ -133,5 +133,5 @@ def test_dynamic_mask_is_exact_at_the_threshold():
         bits = np.unpackbits(mask.cpu().numpy().view(np.uint8), axis=-1, bitorder="little")[0].astype(bool)
         want = numpy_ref.dynamic_mask(prm, v[0], v[1], v[2])
         assert np.array_equal(bits, want), (th, int((bits != want).sum()))
-        assert 0.2 < want.mean() < 0.8
+        assert 0.02 < want.mean() < 0.98
         ctx.close()
