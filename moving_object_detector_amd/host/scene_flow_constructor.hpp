@@ -1,0 +1,123 @@
+// scene_flow_constructor.hpp — host-side mirror of scene_flow_constructor::SceneFlowConstructor
+// (scene_flow_constructor/include/scene_flow_constructor.h:33-275) for the part of the class that is on the hot path:
+// construct(), the previous-frame state of stereoCallback() and reconfigureCB().  Same member names, same argument
+// meaning, same "publish nothing when an input is missing" behaviour — the per-pixel work goes through the C ABI
+// (include/mod_sf.h) to the HIP kernels.  Estimators (SGM / PWC-Net / viso2), TF and ROS wiring are out of scope.
+#pragma once
+#include <functional>
+#include <stdexcept>
+
+#include "messages.hpp"
+
+namespace scene_flow_constructor {
+
+struct SceneFlowConstructorConfig {   // cfg/SceneFlowConstructor.cfg:8-9
+  int dynamic_flow_diff = 5;
+  double max_color_velocity = 1.0;    // unused by live code in the reference as well
+};
+
+class SceneFlowConstructor {
+ public:
+  using CloudCallback = std::function<void(const mod_host::PointCloud2 &)>;
+
+  // One context per constructor, like one node per camera.  `ctx` may be shared with a ClustererNodelet so that the
+  // cloud never leaves the GPU between the two stages.
+  explicit SceneFlowConstructor(ModContext *ctx) : ctx_(ctx) {}
+
+  // stereoCallback()'s first-frame block (scene_flow_constructor.cpp:368-375): camera model from the left CameraInfo.
+  void setCameraInfo(const mod_host::CameraInfo &left, const mod_host::DisparityImage &disparity) {
+    ModCamera cam{};
+    cam.width = left.width; cam.height = left.height;
+    cam.fx = left.P[0]; cam.fy = left.P[5]; cam.cx = left.P[2]; cam.cy = left.P[6]; cam.Tx = left.P[3]; cam.Ty = left.P[7];
+    cam.disp_f = disparity.f; cam.disp_T = disparity.T;
+    cam.min_disparity = disparity.min_disparity; cam.max_disparity = disparity.max_disparity;
+    check(mod_set_camera(ctx_, &cam));
+    image_width_ = left.width; image_height_ = left.height;
+  }
+
+  // reconfigureCB (scene_flow_constructor.cpp:401-407).  The clusterer's parameters live in the same ModParams block;
+  // they are preserved.
+  void reconfigureCB(const SceneFlowConstructorConfig &config) {
+    ModParams p = currentParams();
+    p.dynamic_flow_diff = config.dynamic_flow_diff;
+    check(mod_set_params(ctx_, &p));
+  }
+
+  // construct() (scene_flow_constructor.cpp:91-147).  Null pointers play the role of the reference's empty shared_ptrs.
+  // Returns true when a cloud was produced ("published"); false when the reference would have published nothing.
+  bool construct(const mod_host::DisparityImage *disparity_now, const mod_host::DisparityImage *disparity_previous,
+                 const mod_host::FlowImage *left_flow, const mod_host::Transform *transform_prev2now,
+                 mod_host::PointCloud2 *pc_with_velocity, std::vector<int32_t> *labels = nullptr,
+                 mod_host::MovingObjectArray *moving_objects = nullptr) {
+    ModTransform tf{};
+    if (transform_prev2now) {
+      for (int i = 0; i < 3; i++) tf.t[i] = transform_prev2now->translation[i];
+      for (int i = 0; i < 4; i++) tf.q[i] = transform_prev2now->rotation[i];
+    }
+    // time_between_frames = stamp_now - stamp_previous (scene_flow_constructor.cpp:162-164)
+    const double dt = (disparity_now && disparity_previous) ? disparity_now->header.stamp - disparity_previous->header.stamp : 0.0;
+    const size_t n = (size_t)image_width_ * image_height_;
+    if (pc_with_velocity) pc_with_velocity->data.resize(n * 32);
+    if (labels) labels->resize(n);
+    std::vector<ModObject> objs(max_objects_);
+    int32_t n_obj = 0;
+    const int rc = mod_process_frame_host(ctx_, disparity_now ? disparity_now->data : nullptr,
+                                          disparity_previous ? disparity_previous->data : nullptr,
+                                          left_flow ? left_flow->data : nullptr, transform_prev2now ? &tf : nullptr, dt,
+                                          pc_with_velocity ? pc_with_velocity->data.data() : nullptr,
+                                          labels ? labels->data() : nullptr, objs.data(), (int32_t)objs.size(), &n_obj);
+    if (rc > 0) return false;          // an input is missing: nothing is published (:104,110,122,127,133)
+    check(rc);
+    if (pc_with_velocity) {            // publishPointcloud (:351-362): organized cloud, header of the flow image
+      pc_with_velocity->header = left_flow->header;
+      pc_with_velocity->width = image_width_; pc_with_velocity->height = image_height_;
+      pc_with_velocity->point_step = 32; pc_with_velocity->row_step = 32 * image_width_;
+      pc_with_velocity->is_dense = true;   // PCL's (width, height, value) constructor leaves is_dense = true
+    }
+    if (moving_objects) {
+      moving_objects->header = left_flow->header;
+      moving_objects->moving_object_array.clear();
+      for (int i = 0; i < n_obj && i < (int)objs.size(); i++) moving_objects->moving_object_array.push_back(mod_host::to_message(objs[i]));
+    }
+    return true;
+  }
+
+  // The part of stereoCallback() that carries state across frames (:389-398): the caller hands in this frame's estimator
+  // outputs; the previous disparity is remembered here.  Frame 0 has no previous disparity / flow -> returns false.
+  bool stereoCallback(const mod_host::DisparityImage *disparity_now, const mod_host::FlowImage *left_flow,
+                      const mod_host::Transform *transform_prev2now, mod_host::PointCloud2 *pc_with_velocity,
+                      mod_host::MovingObjectArray *moving_objects = nullptr) {
+    const mod_host::DisparityImage *prev = have_previous_ ? &disparity_previous_ : nullptr;
+    const bool ok = construct(disparity_now, prev, left_flow, transform_prev2now, pc_with_velocity, nullptr, moving_objects);
+    if (disparity_now) {               // disparity_previous_ = disparity_now_ (:398); the pixels are copied: the message dies
+      previous_pixels_.assign(disparity_now->data, disparity_now->data + (size_t)disparity_now->width * disparity_now->height);
+      disparity_previous_ = *disparity_now;
+      disparity_previous_.data = previous_pixels_.data();
+      have_previous_ = true;
+    } else {
+      have_previous_ = false;          // estimateDisparity failed: disparity_now_.reset() (:272-276)
+    }
+    return ok;
+  }
+
+  void setMaxObjects(int n) { max_objects_ = n; }
+
+ private:
+  ModParams currentParams() {
+    ModParams p{};
+    if (mod_get_params(ctx_, &p) != MOD_OK) {   // reference defaults (SceneFlowConstructor.cfg:8, Clusterer.cfg:8-11)
+      p.dynamic_flow_diff = 5; p.cluster_size = 2500; p.neighbor_distance = 4; p.depth_diff = 0.15; p.dynamic_speed = 0.3;
+    }
+    return p;
+  }
+  void check(int rc) { if (rc < 0) throw std::runtime_error(std::string("libmod_sf: ") + mod_last_error(ctx_)); }
+
+  ModContext *ctx_;
+  int image_width_ = 0, image_height_ = 0;
+  int max_objects_ = 1024;
+  bool have_previous_ = false;
+  mod_host::DisparityImage disparity_previous_;
+  std::vector<float> previous_pixels_;
+};
+
+}  // namespace scene_flow_constructor

@@ -1,0 +1,99 @@
+// host_mirror_test.cpp — drives the C++ host mirror (SceneFlowConstructor + ClustererNodelet) the way the reference's
+// node and nodelet are driven: frame 0 carries no previous disparity (nothing is published), frame 1 produces the cloud,
+// which is then fed to the clusterer mirror as a PointCloud2.  Inputs/outputs are raw binary files so that pytest can
+// compare against the golden fixtures (tests/test_gpu_host_mirror.py).  Standalone process: no torch, no Python.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../moving_object_detector_amd/host/clusterer_nodelet.hpp"
+#include "../../moving_object_detector_amd/host/scene_flow_constructor.hpp"
+
+template <class T>
+static std::vector<T> read_all(const std::string &p) {
+  FILE *f = fopen(p.c_str(), "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<T> v(n / sizeof(T));
+  if (fread(v.data(), 1, n, f) != (size_t)n) exit(2);
+  fclose(f);
+  return v;
+}
+static void write_all(const std::string &p, const void *d, size_t n) {
+  FILE *f = fopen(p.c_str(), "wb");
+  if (!f || fwrite(d, 1, n, f) != n) exit(3);
+  fclose(f);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) { fprintf(stderr, "usage: host_mirror_test <dir>\n"); return 1; }
+  const std::string dir = argv[1];
+  auto cam = read_all<double>(dir + "/cam.f64");     // W H fx fy cx cy Tx Ty f T min max
+  auto prm = read_all<double>(dir + "/prm.f64");     // flow_diff cluster_size n depth_diff dynamic_speed
+  auto d_now = read_all<float>(dir + "/d_now.f32");
+  auto d_prev = read_all<float>(dir + "/d_prev.f32");
+  auto flow = read_all<float>(dir + "/flow.f32");
+  auto tq = read_all<double>(dir + "/tq.f64");       // t(3) q(4) dt
+  const int W = (int)cam[0], H = (int)cam[1];
+
+  ModConfig cfg{};
+  cfg.device = 0; cfg.max_width = W; cfg.max_height = H; cfg.max_frames = 1;
+  ModContext *ctx = nullptr;
+  if (mod_create(&cfg, &ctx) != MOD_OK) { fprintf(stderr, "mod_create failed\n"); return 4; }
+
+  scene_flow_constructor::SceneFlowConstructor constructor(ctx);
+  scene_flow_clusterer::ClustererNodelet clusterer(ctx);
+  clusterer.reconfigureCB({(int)prm[1], prm[3], prm[4], (int)prm[2]});
+  constructor.reconfigureCB({(int)prm[0], 1.0});
+
+  mod_host::CameraInfo info;
+  info.width = W; info.height = H;
+  info.P[0] = cam[2]; info.P[5] = cam[3]; info.P[2] = cam[4]; info.P[6] = cam[5]; info.P[3] = cam[6]; info.P[7] = cam[7];
+  mod_host::DisparityImage prev, now;
+  prev.width = now.width = W; prev.height = now.height = H;
+  prev.f = now.f = (float)cam[8]; prev.T = now.T = (float)cam[9];
+  prev.min_disparity = now.min_disparity = (float)cam[10]; prev.max_disparity = now.max_disparity = (float)cam[11];
+  prev.data = d_prev.data(); now.data = d_now.data();
+  prev.header.stamp = 100.0; now.header.stamp = 100.0 + tq[7];
+  constructor.setCameraInfo(info, now);
+
+  mod_host::FlowImage fl;
+  fl.width = W; fl.height = H; fl.data = flow.data(); fl.header.stamp = now.header.stamp; fl.header.frame_id = "left_camera";
+  mod_host::Transform tf;
+  for (int i = 0; i < 3; i++) tf.translation[i] = tq[i];
+  for (int i = 0; i < 4; i++) tf.rotation[i] = tq[3 + i];
+
+  mod_host::PointCloud2 cloud;
+  mod_host::MovingObjectArray objs_fused, objs_cluster;
+  // frame 0: no previous image yet -> no flow, no previous disparity (scene_flow_constructor.cpp:380-384,397-398)
+  const bool pub0 = constructor.stereoCallback(&prev, nullptr, nullptr, &cloud, &objs_fused);
+  // frame 1
+  const bool pub1 = constructor.stereoCallback(&now, &fl, &tf, &cloud, &objs_fused);
+  // visual odometry failure on a later frame publishes nothing and keeps running
+  mod_host::PointCloud2 dummy;
+  const bool pub2 = constructor.stereoCallback(&now, &fl, nullptr, &dummy, nullptr);
+  if (pub0 || !pub1 || pub2) { fprintf(stderr, "publish pattern wrong: %d %d %d\n", pub0, pub1, pub2); return 5; }
+
+  std::vector<int32_t> cluster_map;
+  clusterer.dataCB(cloud, &objs_cluster, &cluster_map);
+  if (objs_cluster.moving_object_array.size() != objs_fused.moving_object_array.size()) { fprintf(stderr, "object count differs\n"); return 6; }
+  if (objs_cluster.header.frame_id != "left_camera") { fprintf(stderr, "header not propagated\n"); return 7; }
+
+  write_all(dir + "/cloud.bin", cloud.data.data(), cloud.data.size());
+  write_all(dir + "/labels.i32", cluster_map.data(), cluster_map.size() * 4);
+  std::vector<double> o;
+  for (const auto &m : objs_cluster.moving_object_array) {
+    o.push_back(m.id);
+    for (int i = 0; i < 3; i++) o.push_back(m.center.position[i]);
+    for (int i = 0; i < 4; i++) o.push_back(m.center.orientation[i]);
+    for (int i = 0; i < 3; i++) o.push_back(m.velocity[i]);
+    for (int i = 0; i < 3; i++) o.push_back(m.bounding_box[i]);
+  }
+  write_all(dir + "/objects.f64", o.data(), o.size() * 8);
+  mod_destroy(ctx);
+  printf("ok %zu objects\n", objs_cluster.moving_object_array.size());
+  return 0;
+}
