@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   __shared__ float zt[G];
   __shared__ int Lt[G];
   __shared__ uint64_t m0[PH], mL[PH];
+  __shared__ int rowlab[PH];                        // common label of a row's dynamic interior pixels, -1 if they differ
   constexpr int kSlots = 32;
   __shared__ int s_any, s_nreq, s_nslots;
   __shared__ CompRec srec[kSlots];
@@ -263,20 +264,33 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX], mu = m0[rr + NMAX - 1];
-    if ((mw & mu) == 0) continue;                    // wave-uniform
+    if ((mw & mu) == 0 || (c.debug & 2048)) continue;                    // wave-uniform
     const bool v = ((mw & mu) >> lane) & 1ull;
     const bool link = v && !(fabsf(zt[me] - zt[me - PW]) > th);
     int cur = ld_relaxed(&Lt[me]), last = -1;
-    wave_unite_lds(Lt, link, cur, last, ld_relaxed(&Lt[me - PW]), lane);
+    if (rr == 0) {                                   // wave-uniform: the row above is the halo, its cells are unhooked
+      if (link) atomicMin(&Lt[me - PW], cur);
+    } else {
+      wave_unite_lds(Lt, link, cur, last, ld_relaxed(&Lt[me - PW]), lane);
+    }
     upr[j] = upr[j] || link;
   }
   lds_barrier();
-  // ---- phase A3: flatten, so that phase B can compare labels directly ----------------------------------------------------
+  // ---- phase A3: flatten, so that phase B can compare labels directly; note rows whose dynamic pixels share one label --
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
-    if ((m0[rr + NMAX] >> lane) & 1ull) { const int r = lds_find(Lt, me); if (r != me) Lt[me] = r; }
+    const uint64_t mw = m0[rr + NMAX];
+    const bool dyn = (mw >> lane) & 1ull;
+    int lab = -1;
+    if (dyn) { lab = lds_find(Lt, me); if (lab != me) Lt[me] = lab; }
+    if (mw) {                                        // wave-uniform
+      const int first = __shfl(lab, __ffsll((unsigned long long)mw) - 1);
+      const bool same = __ballot(dyn && lab != first) == 0;
+      if (lane == 0) rowlab[rr + NMAX] = same ? first : -1;
+    } else if (lane == 0) rowlab[rr + NMAX] = -1;
   }
+  if (tid < NMAX) rowlab[tid] = -1;                  // halo rows: every cell is its own node
   lds_barrier();
   STAMP(1)
   // ---- phase B: the rest of the up-left window --------------------------------------------------------------------------
@@ -285,16 +299,21 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j;
     const uint64_t mw = m0[rr + NMAX];
-    if (mw == 0) continue;                           // wave-uniform
+    if (mw == 0 || (c.debug & 256)) continue;                           // wave-uniform
     const bool dyn = (mw >> lane) & 1ull;
     const int me = (rr + NMAX) * PW + NMAX + lane;
     const float zp = zt[me];
     int cur = dyn ? ld_relaxed(&Lt[me]) : -1, last = -1;
     bool up = upr[j];
+    if (prof && lane == 0) atomicAdd(&a.dbg[13], 1ull);
     for (int dv = 0; dv <= n; dv++) {
       const int qg = rr + NMAX - dv;                 // grid row of the window row
       const uint64_t q0 = m0[qg], qL = mL[qg];
       if ((q0 | qL) == 0) continue;                  // wave-uniform
+      // Window row and own row carry one common label and nothing dynamic sits in the left halo: no union can come out
+      // of this row; it is only needed by lanes that still look for their first up-left edge.
+      const int rl = rowlab[qg];
+      if (rl >= 0 && rl == rowlab[rr + NMAX] && (qL >> (64 - n)) == 0 && __ballot(dyn && !up) == 0) continue;
       // bit i of nb = pixel (lane - n + i) of the window row is dynamic  (i = n - k)
       uint32_t nb;
       if (lane >= n) nb = (uint32_t)(q0 >> (lane - n));
@@ -302,20 +321,46 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
       nb = dyn ? (nb & kmask) : 0u;
       if (dv == 0) nb &= ~(1u << n);                 // k == 0 is p itself
       if (__ballot(nb != 0) == 0) continue;          // wave-uniform
+      if (prof && lane == 0) atomicAdd(&a.dbg[9], 1ull);
       const int base = qg * PW + NMAX + lane;
+      // pass 1, branch-free: all LDS reads first, then one bit per window position (k = columns to the left)
+      float zq[NMAX + 1];
+      int lq[NMAX + 1];
+#pragma unroll
+      for (int k = 0; k <= NMAX; k++) { zq[k] = zt[base - k]; lq[k] = ld_relaxed(&Lt[base - k]); }
+      uint32_t gmask = 0, dmask = 0;                 // bit k: depth gate passes / label differs from this pixel's
 #pragma unroll
       for (int k = 0; k <= NMAX; k++) {
-        if (k > n || (dv == 0 && k == 0)) continue;  // wave-uniform
-        const bool bit = (nb >> (n - k)) & 1u;
-        // already linked: (0,-1) inside the wave is the run link of phase A1, (-1,0) the vertical link of phase A2
-        const bool pre = (dv == 0 && k == 1 && lane > 0) || (dv == 1 && k == 0);
-        const bool valid = bit && !pre && !(fabsf(zp - zt[base - k]) > th);   // depthDiff gate (:194); NaN links
-        up = up || valid;
-        if (!(c.debug & 1)) {
-          bool need = false;
-          int lab = 0;
-          if (valid) { lab = ld_relaxed(&Lt[base - k]); need = lab != cur && lab != last; }
-          if (__ballot(need)) wave_unite_lds(Lt, need, cur, last, lab, lane);
+        gmask |= (fabsf(zp - zq[k]) > th) ? 0u : (1u << k);   // depthDiff gate (:194); NaN links
+        dmask |= (lq[k] != cur) ? (1u << k) : 0u;
+      }
+      // nb holds pixel (lane - n + i) at bit i: reverse it so that bit k = pixel (lane - k)
+      uint32_t vmask = (__brev(nb) >> (31 - n)) & gmask;
+      // (0,0) is p itself; (0,-1) inside the wave is the run link of phase A1, (-1,0) the vertical link of phase A2
+      if (dv == 0) vmask &= (lane > 0) ? ~3u : ~1u;
+      if (dv == 1) vmask &= ~1u;
+      // halo cells (the whole row when it lies above the tile, else the columns left of it) are nodes of their own
+      const uint32_t hmask = (qg < NMAX) ? ~0u : ((lane < 31) ? ~((2u << lane) - 1u) : 0u);
+      bool need_any = (vmask & dmask & ~hmask) != 0;
+      const uint32_t hv = vmask & hmask;
+      if (__ballot(hv != 0)) {
+        // hook the halo cell straight under this pixel's label — one LDS atomic instead of a find/unite through the halo
+        // node; if it already hung under another interior label, those two sets must meet (pass 2)
+#pragma unroll
+        for (int k = 0; k <= NMAX; k++) {
+          if ((hv >> k) & 1u) { const int old = atomicMin(&Lt[base - k], cur); need_any = need_any || (old < kHaloBit && old != cur); }
+        }
+      }
+      up = up || (vmask != 0);
+      // pass 2, rare after A1-A3: unions, one window position at a time
+      if (!(c.debug & 1) && __ballot(need_any)) {
+        if (prof && lane == 0) { atomicAdd(&a.dbg[10], 1ull); atomicAdd(&a.dbg[11], (unsigned long long)__popcll(__ballot(need_any))); }
+#pragma unroll
+        for (int k = 0; k <= NMAX; k++) {
+          if (k > n || (dv == 0 && k == 0)) continue;
+          const int lab = ld_relaxed(&Lt[base - k]);
+          const bool need = ((vmask >> k) & 1u) && lab != cur && lab != last;
+          if (__ballot(need)) { if (prof && lane == 0) atomicAdd(&a.dbg[12], 1ull); wave_unite_lds(Lt, need, cur, last, lab, lane); }
         }
       }
     }
@@ -356,7 +401,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     const int topcells = n * (64 + n);               // n rows x (n + 64) columns above the tile
     const int total = topcells + TH * n;             // + TH rows x n columns left of it
     uint2 *req = a.requests + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * a.req_cap;
-    for (int i0 = 0; i0 < total; i0 += 256) {
+    for (int i0 = 0; i0 < total && !(c.debug & 1024); i0 += 256) {
       const int i = i0 + tid;
       bool linked = false;
       int hg = 0, rg = 0;
@@ -410,7 +455,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = r0 + j, gy = y0 + rr;
-    if (m0[rr + NMAX] == 0 || (c.debug & 8)) continue;                // wave-uniform
+    if (m0[rr + NMAX] == 0 || (c.debug & 520)) continue;                // wave-uniform
     const int rg = rootg[j];
     uint32_t ox = 0, oy = 0, oz = 0, key = (uint32_t)kKeyNone;
     int slot = -1, over = -1;
