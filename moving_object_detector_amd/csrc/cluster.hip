@@ -201,9 +201,15 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     return;
   }
   const float th = c.depth_th;
+#ifdef MOD_PHASE_COUNTERS   // diagnostic build only (make PHASE_COUNTERS=1): per-phase cycle sums in ClArgs.dbg
   const bool prof = c.debug & 128;
   unsigned long long t0 = prof ? clock64() : 0, t1;
 #define STAMP(i) if (prof) { t1 = clock64(); if (lane == 0) { atomicAdd(&a.dbg[i], t1 - t0); atomicMax(&a.dbg[16 + i], t1 - t0); } t0 = t1; }
+#define COUNT(i, v) if (prof && lane == 0) atomicAdd(&a.dbg[i], (unsigned long long)(v));
+#else
+#define STAMP(i)
+#define COUNT(i, v)
+#endif
   // ---- phase A: masked depth + identity parents; grid row gr = image row y0 - NMAX + gr, 4 rows per step -----------
   // All HBM reads of the kernel are issued here, unconditionally (clamped addresses, values of non-dynamic pixels are
   // discarded): predicated loads would compile to one exec-masked branch + wait each, i.e. one round trip per row.
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
     const float zp = zt[me];
     int cur = dyn ? ld_relaxed(&Lt[me]) : -1, last = -1;
     bool up = upr[j];
-    if (prof && lane == 0) atomicAdd(&a.dbg[13], 1ull);
+    COUNT(13, 1)
     for (int dv = 0; dv <= n; dv++) {
       const int qg = rr + NMAX - dv;                 // grid row of the window row
       const uint64_t q0 = m0[qg], qL = mL[qg];
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
       nb = dyn ? (nb & kmask) : 0u;
       if (dv == 0) nb &= ~(1u << n);                 // k == 0 is p itself
       if (__ballot(nb != 0) == 0) continue;          // wave-uniform
-      if (prof && lane == 0) atomicAdd(&a.dbg[9], 1ull);
+      COUNT(9, 1)
       const int base = qg * PW + NMAX + lane;
       // pass 1, branch-free: all LDS reads first, then one bit per window position (k = columns to the left)
       float zq[NMAX + 1];
@@ -354,13 +360,13 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
       up = up || (vmask != 0);
       // pass 2, rare after A1-A3: unions, one window position at a time
       if (!(c.debug & 1) && __ballot(need_any)) {
-        if (prof && lane == 0) { atomicAdd(&a.dbg[10], 1ull); atomicAdd(&a.dbg[11], (unsigned long long)__popcll(__ballot(need_any))); }
+        COUNT(10, 1)
 #pragma unroll
         for (int k = 0; k <= NMAX; k++) {
           if (k > n || (dv == 0 && k == 0)) continue;
           const int lab = ld_relaxed(&Lt[base - k]);
           const bool need = ((vmask >> k) & 1u) && lab != cur && lab != last;
-          if (__ballot(need)) { if (prof && lane == 0) atomicAdd(&a.dbg[12], 1ull); wave_unite_lds(Lt, need, cur, last, lab, lane); }
+          if (__ballot(need)) { COUNT(12, 1) wave_unite_lds(Lt, need, cur, last, lab, lane); }
         }
       }
     }
@@ -476,6 +482,7 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   }
   STAMP(8)
 #undef STAMP
+#undef COUNT
   if (tid == 0) { hdr[0] = 1; hdr[1] = s_nreq; }   // s_nreq is final: the barrier after the request loop has passed
 }
 
@@ -599,47 +606,108 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
   }
 }
 
-// Final labels + member compaction, one workgroup per tile: labels[p] = new label of p's component or -1 (the whole
-// plane is written here, 4 B/px); members of surviving clusters append (||v|| bits, pixel) to their cluster's segment,
-// one cursor atomic per (wave row, cluster).
+// Final labels + member compaction, one workgroup per tile.  labels[p] = new label of p's component or -1 (the whole
+// plane is written here, 4 B/px).  A pixel's parent entry names its tile root, so the few tile roots resolve their final
+// root's new label once (into LDS) and every pixel just looks it up; members of surviving clusters are counted per tile
+// root in LDS, one cursor atomic per (tile root) reserves their slots, then (||v|| bits, pixel) records are appended.
 template <int TH>
 __global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
+  constexpr int RPW = TH / 4;
+  __shared__ int nlmap[TH * 64];                     // per tile-root cell: new label of its component (or -1)
+  __shared__ int lcount[TH * 64];                    // per tile-root cell: member count, then base slot of its members
   const int wi = blockIdx.x, f = blockIdx.z, lane = threadIdx.x, w = threadIdx.y;
   const size_t tidx = (size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi;
-  const bool active = a.tilehdr[tidx * 2] != 0;
   const size_t N = (size_t)c.W * c.H;
   const size_t fN = (size_t)f * N;
-  const int x = wi * 64 + lane;
-  for (int j = w; j < TH; j += 4) {
-    const int y = blockIdx.y * TH + j;
-    if (y >= c.H) break;
-    const int p = y * c.W + x;
-    int nl = -1;
-    uint32_t nb = 0;
-    uint64_t mword = 0;
-    if (active) mword = a.mask[((size_t)f * c.H + y) * c.mask_words + wi];
-    if ((mword >> lane) & 1ull) {
-      const int lr = a.parent[fN + p];                    // tile root ...
-      const int r = a.parent[fN + lr];                    // ... whose entry names the final root (k_ccl_merge)
-      nl = a.comps[fN + r].key;                           // new label of the component, or -1
-      if (nl >= 0) nb = __float_as_uint(norm3_f32(a.vx[fN + p], a.vy[fN + p], a.vz[fN + p]));
+  const int x0 = wi * 64, y0 = blockIdx.y * TH, r0 = w * RPW, x = x0 + lane;
+  if (a.tilehdr[tidx * 2] == 0) {                    // nothing dynamic in the tile
+#pragma unroll
+    for (int j = 0; j < RPW; j++) { const int y = y0 + r0 + j; if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = -1; }
+    return;
+  }
+  // ---- all row-independent HBM reads up front (clamped addresses, results of non-dynamic lanes are ignored) ----
+  const int xc = min(x, c.W - 1);
+  uint64_t mw[RPW], rw[RPW];
+  int par[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    const int y = y0 + r0 + j, yc = min(y, c.H - 1);
+    const size_t wo = ((size_t)f * c.H + yc) * c.mask_words + wi;
+    mw[j] = (y < c.H) ? a.mask[wo] : 0ull;
+    rw[j] = (y < c.H) ? a.lroot[wo] : 0ull;
+    par[j] = a.parent[fN + (size_t)yc * c.W + xc];
+  }
+  // ---- tile roots: their parent entry names the final root (k_ccl_merge), whose record holds the new label ----
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    if ((rw[j] >> lane) & 1ull) {
+      const int cell = (r0 + j) * 64 + lane;
+      nlmap[cell] = a.comps[fN + par[j]].key;
+      lcount[cell] = 0;
     }
-    if (x < c.W) a.labels[fN + p] = nl;
-    uint64_t todo = __ballot(nl >= 0);
-    while (todo) {
-      const int leader = __ffsll((unsigned long long)todo) - 1;
-      const int l = __shfl(nl, leader);
-      const bool mine = (nl == l);
-      const uint64_t grp = __ballot(mine);
+  }
+  lds_barrier();
+  // ---- labels; members counted per tile root ----
+  const float invW = 1.0f / (float)c.W;
+  const int tile0 = y0 * c.W + x0;
+  int nl[RPW], cell[RPW], rank[RPW];
+  bool any_member = false;
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    const int y = y0 + r0 + j;
+    const bool dyn = (mw[j] >> lane) & 1ull;
+    // tile-local coordinates of the tile root: d = ly * W + lx with lx < 64, ly < TH, so (d + 0.5) / W truncates to ly exactly
+    const int d = par[j] - tile0;
+    const int ly = (int)(((float)d + 0.5f) * invW);
+    // a tile root's own entry was redirected to the final root (possibly in another tile) by k_ccl_merge: it is its own cell
+    const bool isroot = (rw[j] >> lane) & 1ull;
+    const int cl = !dyn ? 0 : isroot ? ((r0 + j) * 64 + lane) : (ly * 64 + (d - ly * c.W));
+    const int l = dyn ? nlmap[cl] : -1;
+    nl[j] = l; cell[j] = cl; rank[j] = 0;
+    if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = l;
+    const uint64_t mb = __ballot(l >= 0);
+    if (mb) {                                        // wave-uniform
+      any_member = true;
+      // lanes that share the first member's tile root reserve ranks with one LDS atomic; stragglers use their own
+      const int lead = __ffsll((unsigned long long)mb) - 1;
+      const int c0 = __shfl(cl, lead);
+      const bool grp = l >= 0 && cl == c0;
+      const uint64_t gb = __ballot(grp);
       int base = 0;
-      if (lane == leader) base = atomicAdd(&a.cursors[(size_t)f * a.max_objects + l], __popcll((unsigned long long)grp));
-      base = __shfl(base, leader);
-      if (mine) {
-        const int rank = __popcll((unsigned long long)(grp & ((1ull << lane) - 1ull)));
-        const int off = a.clusters[(size_t)f * a.max_objects + l].offset;
-        a.members[fN + off + base + rank] = make_uint2(nb, (uint32_t)p);
+      if (lane == lead) base = atomicAdd(&lcount[c0], __popcll((unsigned long long)gb));
+      base = __shfl(base, lead);
+      if (grp) rank[j] = base + __popcll((unsigned long long)(gb & ((1ull << lane) - 1ull)));
+      else if (l >= 0) rank[j] = atomicAdd(&lcount[cl], 1);
+    }
+  }
+  // velocity of the wave's members (needed for the ||v|| bits), issued before the barriers
+  float vx[RPW], vy[RPW], vz[RPW];
+  if (any_member) {
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const size_t gp = fN + (size_t)min(y0 + r0 + j, c.H - 1) * c.W + xc;
+      vx[j] = a.vx[gp]; vy[j] = a.vy[gp]; vz[j] = a.vz[gp];
+    }
+  }
+  lds_barrier();
+  // ---- one cursor atomic per tile root with members ----
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    if ((rw[j] >> lane) & 1ull) {
+      const int cl = (r0 + j) * 64 + lane;
+      const int l = nlmap[cl], cnt = lcount[cl];
+      if (l >= 0 && cnt > 0)
+        lcount[cl] = a.clusters[(size_t)f * a.max_objects + l].offset + atomicAdd(&a.cursors[(size_t)f * a.max_objects + l], cnt);
+    }
+  }
+  lds_barrier();
+  if (any_member) {
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      if (nl[j] >= 0) {
+        const int p = (y0 + r0 + j) * c.W + x;
+        a.members[fN + lcount[cell[j]] + rank[j]] = make_uint2(__float_as_uint(norm3_f32(vx[j], vy[j], vz[j])), (uint32_t)p);
       }
-      todo &= ~grp;
     }
   }
 }
@@ -687,7 +755,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     bool in_lds = false;                     // the live range has been copied to `cand`
     int cn = 0;
     uint32_t val = 0;
-    while (true) {
+    for (int round = 0; round < 8; round++) {        // <= 3 narrowing rounds per source; the bound only guards against corrupt input
       const uint32_t range = hi - lo;
       const int shift = range < (uint32_t)kMedBins ? 0 : (32 - __clz((int)range) - 11);   // (range >> shift) < 2048
       // ---- histogram of the live range (from HBM until it fits the LDS list, then from LDS) ----
@@ -781,7 +849,8 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
       }
     }
     __syncthreads();
-    const uint32_t best = (uint32_t)(s_best & 0xffffffffull);
+    uint32_t best = (uint32_t)(s_best & 0xffffffffull);
+    if (s_best == ~0ull) best = seg[0].y;            // unreachable for consistent input; keeps every access in bounds
     const float bvx = a.vx[(size_t)f * N + best], bvy = a.vy[(size_t)f * N + best], bvz = a.vz[(size_t)f * N + best];
     for (int i = tid; i < tn; i += kMedThreads) {
       const uint2 m = from_lds ? cand[i] : seg[i];
