@@ -38,16 +38,24 @@ __device__ __forceinline__ void iso_apply(const FrameConst &fc, float X, float Y
   oz = (float)(fc.m[11] + (fc.m[8] * x + (fc.m[9] * y + fc.m[10] * z)));
 }
 
-// One pixel of constructVelocityPC with everything it depends on.
-//   dn  : disparity_now(x, y)      dpo : disparity_prev(x, y)      f0,f1 : flow(x, y)
-//   rx,ry : F64 pixel ray of (x, y)
-__device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, const float *__restrict__ dprev, int x, int y,
-                                         float dn, float dpo, float f0, float f1, double rx, double ry, Px &o) {
+// One pixel of constructVelocityPC with everything it depends on, in two stages so that a thread
+// can issue the data-dependent gathers of all its pixels together (one extra memory round trip per thread, not per pixel).
+//   stage 1: static flow at the own pixel, now point, warp target        (needs dn, dpo, flow, own rays)
+//   stage 2: previous point at the warp target, residual test, velocity   (needs disp_prev / rays AT the warp target)
+struct PxState {
+  float Xn, Yn, zn, f0, f1;
+  int px, py;          // warp target, clamped into the image when `go` is false
+  bool go;             // every test before the gather passed
+};
+
+__device__ __forceinline__ void sf_stage1(const DevCam &c, const FrameConst &fc, int x, int y, float dn, float dpo, float f0,
+                                          float f1, double rx, double ry, Px &o, PxState &st) {
   const float nan = __uint_as_float(0x7fc00000u);
   o.x = o.y = o.z = o.vx = o.vy = o.vz = nan;
   o.s0 = o.s1 = nan;
   o.depth = nan;
   o.dyn = false;
+  st.go = false; st.px = 0; st.py = 0; st.f0 = f0; st.f1 = f1;
 
   // ---- static flow at the own pixel: reproject prev, transform, project (always needed by the residual test) ----
   {
@@ -72,6 +80,7 @@ __device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, 
   const float zn = c.fT / dn;
   const float Xn = (float)(rx * (double)zn);
   const float Yn = (float)(ry * (double)zn);
+  st.Xn = Xn; st.Yn = Yn; st.zn = zn;
   if (okn) o.depth = zn;                                    // toDepthImage (disparity_image_processor.cpp:105-120)
   if (!(okn && !isnan(Xn) && !isinf(Xn))) return;           // isValid tests x only (scene_flow_constructor.h:240-249)
   o.x = Xn; o.y = Yn; o.z = zn;
@@ -83,35 +92,48 @@ __device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, 
   if (isnan(dn) || isinf(dn) || dn < 0.0f) return;          // getRightPoint(now)
   // out-of-int-range warps are UB in the reference (x86 yields INT_MIN -> rejected by the bounds test): reject.
   if (!(rxf >= 0.0f && rxf < (float)c.W && ryf >= 0.0f && ryf < (float)c.H)) return;
-  const int px = (int)rxf, py = (int)ryf;
-  const float dpw = dprev[(size_t)py * c.W + px];           // the one data-dependent gather
+  if (isnan(o.s0)) return;                                  // static flow NaN (scene_flow_constructor.cpp:193)
+  st.px = (int)rxf; st.py = (int)ryf;
+  st.go = true;
+}
+
+//   dpw = disparity_prev at the warp target, rpx / rpy = F64 rays of its column / row
+__device__ __forceinline__ void sf_stage2(const DevCam &c, const FrameConst &fc, const PxState &st, float dpw, double rpx,
+                                          double rpy, Px &o) {
+  if (!st.go) return;
   if (!disp_in_range(c, dpw)) return;                       // getRightPoint(previous): getDisparity ...
   if (isnan(dpw) || isinf(dpw) || dpw < 0.0f) return;       // ... then NaN / inf / negative
   if (dpw == 0.0f) return;                                  // prev cloud holds NaN there -> !isValid
   const float zp = c.fT / dpw;
-  const float Xp = (float)(c.rayx[px] * (double)zp);
-  const float Yp = (float)(c.rayy[py] * (double)zp);
+  const float Xp = (float)(rpx * (double)zp);
+  const float Yp = (float)(rpy * (double)zp);
   if (isnan(Xp)) return;                                    // NaN passes through the transform untouched -> invalid
   float tx, ty, tz;
   iso_apply(fc, Xp, Yp, zp, tx, ty, tz);
   if (isnan(tx) || isinf(tx)) return;
-  if (isnan(o.s0)) return;                                  // static flow NaN (scene_flow_constructor.cpp:193)
 
   // ---- residual test and velocity (scene_flow_constructor.cpp:196-209) ----
-  const float r0 = f0 - o.s0, r1 = f1 - o.s1;
+  const float r0 = st.f0 - o.s0, r1 = st.f1 - o.s1;
   float acc = 0.0f;
   acc = acc + r0 * r0;
   acc = acc + r1 * r1;
   if (sqrtf(acc) >= c.flow_th) {
-    o.vx = (float)((double)(Xn - tx) / fc.dt);
-    o.vy = (float)((double)(Yn - ty) / fc.dt);
-    o.vz = (float)((double)(zn - tz) / fc.dt);
+    o.vx = (float)((double)(st.Xn - tx) / fc.dt);
+    o.vy = (float)((double)(st.Yn - ty) / fc.dt);
+    o.vz = (float)((double)(st.zn - tz) / fc.dt);
     // calculateDynamicMap: (double)||v|| >= dynamic_speed, folded into an equivalent F32 threshold on the host
     o.dyn = norm3_f32(o.vx, o.vy, o.vz) >= c.speed_th;
   } else {
     o.vx = 0.0f; o.vy = 0.0f; o.vz = 0.0f;
     o.dyn = 0.0f >= c.speed_th;
   }
+}
+
+__device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, const float *__restrict__ dprev, int x, int y,
+                                         float dn, float dpo, float f0, float f1, double rx, double ry, Px &o) {
+  PxState st;
+  sf_stage1(c, fc, x, y, dn, dpo, f0, f1, rx, ry, o, st);
+  sf_stage2(c, fc, st, dprev[(size_t)st.py * c.W + st.px], c.rayx[st.px], c.rayy[st.py], o);
 }
 
 // OR-combine the 4-bit nibbles of 16 consecutive lanes into one 64-bit word (lane 16k -> word k of the wave).
@@ -145,10 +167,20 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     const double2 rxb = *reinterpret_cast<const double2 *>(c.rayx + x0 + 2);
     const float *dprev_f = a.dprev + (size_t)f * N;
     Px p0, p1, p2, p3;
-    sf_pixel(c, fc, dprev_f, x0 + 0, y, dn.x, dp.x, fa.x, fa.y, rxa.x, ry, p0);
-    sf_pixel(c, fc, dprev_f, x0 + 1, y, dn.y, dp.y, fa.z, fa.w, rxa.y, ry, p1);
-    sf_pixel(c, fc, dprev_f, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2);
-    sf_pixel(c, fc, dprev_f, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3);
+    PxState s0, s1, s2, s3;
+    sf_stage1(c, fc, x0 + 0, y, dn.x, dp.x, fa.x, fa.y, rxa.x, ry, p0, s0);
+    sf_stage1(c, fc, x0 + 1, y, dn.y, dp.y, fa.z, fa.w, rxa.y, ry, p1, s1);
+    sf_stage1(c, fc, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2, s2);
+    sf_stage1(c, fc, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3, s3);
+    // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image (clamped) targets
+    const float g0 = dprev_f[(size_t)s0.py * c.W + s0.px], g1 = dprev_f[(size_t)s1.py * c.W + s1.px];
+    const float g2 = dprev_f[(size_t)s2.py * c.W + s2.px], g3 = dprev_f[(size_t)s3.py * c.W + s3.px];
+    const double ax0 = c.rayx[s0.px], ax1 = c.rayx[s1.px], ax2 = c.rayx[s2.px], ax3 = c.rayx[s3.px];
+    const double ay0 = c.rayy[s0.py], ay1 = c.rayy[s1.py], ay2 = c.rayy[s2.py], ay3 = c.rayy[s3.py];
+    sf_stage2(c, fc, s0, g0, ax0, ay0, p0);
+    sf_stage2(c, fc, s1, g1, ax1, ay1, p1);
+    sf_stage2(c, fc, s2, g2, ax2, ay2, p2);
+    sf_stage2(c, fc, s3, g3, ax3, ay3, p3);
     *reinterpret_cast<float4 *>(a.x + base) = make_float4(p0.x, p1.x, p2.x, p3.x);
     *reinterpret_cast<float4 *>(a.y + base) = make_float4(p0.y, p1.y, p2.y, p3.y);
     *reinterpret_cast<float4 *>(a.z + base) = make_float4(p0.z, p1.z, p2.z, p3.z);
