@@ -7,7 +7,8 @@ resident in HBM when the timed region starts.  Multi-GPU = frame sharding (weak 
 the only collective is the RCCL broadcast of the camera-intrinsics/parameter block before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
-  roofline     — the dominant kernel group, priced with SURVEY.md §8(d)'s algorithmic bytes per pixel
+  roofline     — the dominant kernel (longest average launch, HIP events around every kernel on the launch stream),
+                 priced with SURVEY.md §8(d)'s algorithmic bytes per pixel; per-kernel and per-group numbers alongside
   cpu_baseline — the CPU oracle ("port": op-for-op restatement of the reference loops) timed on this box's host cores
 """
 from __future__ import annotations
@@ -149,8 +150,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    stage = {name: ctx.stage_time(i) for i, name in ((capi.MOD_STAGE_SCENE_FLOW, "scene_flow"), (capi.MOD_STAGE_CCL, "ccl"),
-                                                     (capi.MOD_STAGE_OBJECTS, "objects"))}
+    stage = [ctx.stage_time(i) for i in range(capi.MOD_STAGE_COUNT)]
     ctx.set_profiling(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -161,23 +161,33 @@ def main():
         N = W * H
         pairs = world * F * args.steps
         value = pairs / elapsed
-        per_launch_ms = {k: (v[0] / v[1] if v[1] else float("nan")) for k, v in stage.items()}
-        sf_ms = per_launch_ms["scene_flow"]
-        cl_ms = per_launch_ms["ccl"] + per_launch_ms["objects"]
+        ms = [(t / n if n else float("nan")) for t, n in stage]                 # average launch duration per kernel
+        kernels = {capi.STAGE_NAMES[i]: ms[i] for i in range(capi.MOD_STAGE_COUNT)}
+        sf_ms = ms[capi.MOD_STAGE_SCENE_FLOW]
+        cl_ms = sum(ms[1:])
         sf_gbs = F * N * B_SCENE_FLOW / (sf_ms * 1e-3) / 1e9
         cl_gbs = F * N * B_CLUSTER / (cl_ms * 1e-3) / 1e9
-        dominant = "scene_flow" if sf_ms >= cl_ms else "cluster"
-        ach = sf_gbs if dominant == "scene_flow" else cl_gbs
+        dom = max(range(capi.MOD_STAGE_COUNT), key=lambda i: ms[i])            # the single kernel with the longest launch
+        # algorithmic bytes of that kernel per launch: the scene-flow kernel moves its group's 40 B/px; a cluster kernel is
+        # priced with the whole cluster group's 20 B/px (the group's bytes are not separable per kernel)
+        dom_bytes = F * N * (B_SCENE_FLOW if dom == capi.MOD_STAGE_SCENE_FLOW else B_CLUSTER)
+        ach = dom_bytes / (ms[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")              # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("frames_per_launch") == F and tj.get("width") == W and tj.get("height") == H:
+                traffic = tj["kernels"].get(capi.STAGE_NAMES[dom].split("+")[0], {}).get("hbm_bytes_per_launch")
         roof = {
-            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-            "kernel": "k_scene_flow_v4" if dominant == "scene_flow" else "cluster group (k_ccl_* + k_comp_stats..k_finalize)",
-            "algorithmic_bytes_per_px": B_SCENE_FLOW if dominant == "scene_flow" else B_CLUSTER,
-            "frames_per_launch": F, "avg_launch_ms": sf_ms if dominant == "scene_flow" else cl_ms,
-            "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
+            "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": capi.STAGE_NAMES[dom], "algorithmic_bytes_per_launch": dom_bytes,
+            "algorithmic_bytes_per_px": B_SCENE_FLOW if dom == capi.MOD_STAGE_SCENE_FLOW else B_CLUSTER,
+            "frames_per_launch": F, "avg_launch_ms": ms[dom], "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
+            "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 + WRITE_SIZE, same command)" if traffic else None,
+            "kernels_ms_per_launch": kernels,
             "groups": {
                 "scene_flow": {"ms_per_launch": sf_ms, "GBps": sf_gbs, "frac": sf_gbs / HBM_PEAK_GBS, "bytes_per_px": B_SCENE_FLOW},
-                "cluster": {"ms_per_launch": cl_ms, "GBps": cl_gbs, "frac": cl_gbs / HBM_PEAK_GBS, "bytes_per_px": B_CLUSTER,
-                            "ccl_ms": per_launch_ms["ccl"], "objects_ms": per_launch_ms["objects"]},
+                "cluster": {"ms_per_launch": cl_ms, "GBps": cl_gbs, "frac": cl_gbs / HBM_PEAK_GBS, "bytes_per_px": B_CLUSTER},
                 "fused_end_to_end": {"GBps": F * N * B_FUSED / ((sf_ms + cl_ms) * 1e-3) / 1e9, "bytes_per_px": B_FUSED},
             },
         }

@@ -186,10 +186,14 @@ int  mod_memcpy_d2h(ModContext *ctx, void *host_dst, const void *dev_src, uint64
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 /* Stage timers: when enabled, each stage of the next calls is bracketed by HIP events on the context's stream. */
-#define MOD_STAGE_SCENE_FLOW  0   /* fused scene-flow kernel */
-#define MOD_STAGE_CCL         1   /* mask (if needed) + label propagation + flatten */
-#define MOD_STAGE_OBJECTS     2   /* stats + size filter/order + relabel + median velocity */
-#define MOD_STAGE_COUNT       3
+#define MOD_STAGE_SCENE_FLOW  0   /* k_scene_flow_v4 / _v1: fused scene-flow kernel (+ dynamic mask)            */
+#define MOD_STAGE_CCL_TILE    1   /* k_ccl_tile: tile-local connected components (+ k_dynamic_mask if needed)   */
+#define MOD_STAGE_CCL_LINK    2   /* k_ccl_link: cross-tile unions                                              */
+#define MOD_STAGE_CCL_MERGE   3   /* k_ccl_merge: root-level flatten + record folding                           */
+#define MOD_STAGE_SELECT      4   /* k_select: size filter, reference numbering, bbox/centre                    */
+#define MOD_STAGE_FINAL       5   /* k_final: labels plane + member compaction                                  */
+#define MOD_STAGE_MEDIAN      6   /* k_median + k_finalize: median-velocity member, object ids                  */
+#define MOD_STAGE_COUNT       7
 int  mod_set_profiling(ModContext *ctx, int32_t enable);
 /* Accumulated milliseconds and launch count of a stage since the last reset (synchronises the stream). */
 int  mod_get_stage_time(ModContext *ctx, int32_t stage, double *total_ms, int64_t *calls);

@@ -894,23 +894,29 @@ constexpr int kTileH = 16;
 
 }  // namespace
 
-void launch_ccl(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  dim3 block(64, 4, 1);
-  dim3 tgrid(c.mask_words, (c.H + kTileH - 1) / kTileH, frames);
+static dim3 tile_grid(const DevCam &c, int frames) { return dim3(c.mask_words, (c.H + kTileH - 1) / kTileH, frames); }
+
+void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
+  const dim3 block(64, 4, 1), tgrid = tile_grid(c, frames);
   if (c.n <= 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4>), tgrid, block, 0, s, c, a);
   else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8>), tgrid, block, 0, s, c, a);
   else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16>), tgrid, block, 0, s, c, a);
-  hipLaunchKernelGGL(k_ccl_link<kTileH>, tgrid, dim3(256), 0, s, c, a);
-  hipLaunchKernelGGL(k_ccl_merge<kTileH>, tgrid, block, 0, s, c, a);
 }
-
-void launch_objects(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  dim3 block(64, 4, 1);
-  dim3 tgrid(c.mask_words, (c.H + kTileH - 1) / kTileH, frames);
+void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
+  hipLaunchKernelGGL(k_ccl_link<kTileH>, tile_grid(c, frames), dim3(256), 0, s, c, a);
+}
+void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
+  hipLaunchKernelGGL(k_ccl_merge<kTileH>, tile_grid(c, frames), dim3(64, 4, 1), 0, s, c, a);
+}
+void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // the second ClusterInfo array (rank scratch) lives right behind the first one
   ClusterInfo *tmp = a.clusters + (size_t)frames * a.max_objects;
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
-  hipLaunchKernelGGL(k_final<kTileH>, tgrid, block, 0, s, c, a);
+}
+void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
+  hipLaunchKernelGGL(k_final<kTileH>, tile_grid(c, frames), dim3(64, 4, 1), 0, s, c, a);
+}
+void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   hipLaunchKernelGGL(k_median, dim3(16, frames), dim3(kMedThreads), 0, s, c, a);
   hipLaunchKernelGGL(k_finalize, dim3((frames + 63) / 64), dim3(64), 0, s, c, a, frames);
 }

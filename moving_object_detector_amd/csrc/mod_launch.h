@@ -42,9 +42,12 @@ void launch_pack(size_t n, const float *x, const float *y, const float *z, const
                  void *aos, hipStream_t s);
 void launch_unpack(size_t n, const void *aos, float *x, float *y, float *z, float *vx, float *vy, float *vz, hipStream_t s);
 
-// label propagation: parent init + windowed union + flatten (MOD_STAGE_CCL)
-void launch_ccl(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
-// stats + size filter/order + relabel/member compaction + median velocity + object emission (MOD_STAGE_OBJECTS)
-void launch_objects(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+// clustering kernels, one launcher per timed stage (include/mod_sf.h MOD_STAGE_*)
+void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 int ccl_tile_rows();                 // tile height of k_ccl_tile
 int ccl_request_capacity(int n);     // link requests one tile can emit at neighbor_distance n

@@ -57,8 +57,8 @@ struct ModContext {
   bool profiling = false;
   std::vector<EventPair> pending[MOD_STAGE_COUNT];
   std::vector<EventPair> free_events;
-  double stage_ms[MOD_STAGE_COUNT] = {0, 0, 0};
-  int64_t stage_calls[MOD_STAGE_COUNT] = {0, 0, 0};
+  double stage_ms[MOD_STAGE_COUNT] = {};
+  int64_t stage_calls[MOD_STAGE_COUNT] = {};
   std::string err;
 };
 
@@ -215,15 +215,16 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
   a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
   {
-    StageTimer t(c, MOD_STAGE_CCL);
+    StageTimer t(c, MOD_STAGE_CCL_TILE);
     if (!mask_ready) launch_dynamic_mask(c->dc, frames, pl->vx, pl->vy, pl->vz, (uint64_t *)mask, c->stream);
     HIP_TRY(c, hipMemsetAsync(c->b.counters, 0, sizeof(int32_t) * 8 * frames, c->stream));
-    launch_ccl(c->dc, a, frames, c->stream);
+    launch_ccl_tile(c->dc, a, frames, c->stream);
   }
-  {
-    StageTimer t(c, MOD_STAGE_OBJECTS);
-    launch_objects(c->dc, a, frames, c->stream);
-  }
+  { StageTimer t(c, MOD_STAGE_CCL_LINK); launch_ccl_link(c->dc, a, frames, c->stream); }
+  { StageTimer t(c, MOD_STAGE_CCL_MERGE); launch_ccl_merge(c->dc, a, frames, c->stream); }
+  { StageTimer t(c, MOD_STAGE_SELECT); launch_select(c->dc, a, frames, c->stream); }
+  { StageTimer t(c, MOD_STAGE_FINAL); launch_final(c->dc, a, frames, c->stream); }
+  { StageTimer t(c, MOD_STAGE_MEDIAN); launch_median(c->dc, a, frames, c->stream); }
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;
 }
