@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
   unsigned long long t0 = prof ? clock64() : 0, t1;
 #define STAMP(i) if (prof) { t1 = clock64(); if (lane == 0) { atomicAdd(&a.dbg[i], t1 - t0); atomicMax(&a.dbg[16 + i], t1 - t0); } t0 = t1; }
 #define COUNT(i, v) if (prof && lane == 0) atomicAdd(&a.dbg[i], (unsigned long long)(v));
+#elif defined(MOD_PHASE_MARKERS)
+#define STAMP(i) asm volatile("; PHASE_MARK " #i ::: "memory");
+#define COUNT(i, v)
 #else
 #define STAMP(i)
 #define COUNT(i, v)
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
     }
   }
   lds_barrier();
-  // ---- labels; members counted per tile root ----
+  // ---- labels ----
   const float invW = 1.0f / (float)c.W;
   const int tile0 = y0 * c.W + x0;
   int nl[RPW], cell[RPW], rank[RPW];
@@ -665,9 +668,15 @@ __global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
     const int l = dyn ? nlmap[cl] : -1;
     nl[j] = l; cell[j] = cl; rank[j] = 0;
     if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = l;
-    const uint64_t mb = __ballot(l >= 0);
-    if (mb) {                                        // wave-uniform
-      any_member = true;
+    any_member = any_member || (__ballot(l >= 0) != 0);
+  }
+  // ---- members: counted per tile root in LDS ----
+  if (any_member) {                                  // wave-uniform
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int l = nl[j], cl = cell[j];
+      const uint64_t mb = __ballot(l >= 0);
+      if (mb == 0) continue;                         // wave-uniform
       // lanes that share the first member's tile root reserve ranks with one LDS atomic; stragglers use their own
       const int lead = __ffsll((unsigned long long)mb) - 1;
       const int c0 = __shfl(cl, lead);
@@ -680,7 +689,7 @@ __global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
       else if (l >= 0) rank[j] = atomicAdd(&lcount[cl], 1);
     }
   }
-  // velocity of the wave's members (needed for the ||v|| bits), issued before the barriers
+  // velocity of the wave's members (needed for the ||v|| bits), in flight across the barriers
   float vx[RPW], vy[RPW], vz[RPW];
   if (any_member) {
 #pragma unroll
@@ -705,8 +714,9 @@ __global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       if (nl[j] >= 0) {
-        const int p = (y0 + r0 + j) * c.W + x;
-        a.members[fN + lcount[cell[j]] + rank[j]] = make_uint2(__float_as_uint(norm3_f32(vx[j], vy[j], vz[j])), (uint32_t)p);
+        const size_t slot = fN + lcount[cell[j]] + rank[j];
+        a.mbits[slot] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
+        a.mpix[slot] = (uint32_t)((y0 + r0 + j) * c.W + x);
       }
     }
   }
@@ -716,7 +726,7 @@ __global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
 // (clusterer_nodelet.cpp:168-174).  All norms are finite and >= 0, so their F32 bit patterns order like the values:
 // a range-adaptive 2048-bin histogram over (bits - min) >> shift isolates the bin that holds rank size/2, its members
 // (a handful) are ranked exactly in LDS; degenerate distributions narrow the range and repeat.
-constexpr int kMedThreads = 1024, kMedBins = 2048, kMedCap = 2048, kMedBatch = 8;
+constexpr int kMedThreads = 1024, kMedBins = 2048, kMedCap = 2048, kMedBatch = 16;
 
 __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -731,13 +741,14 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
     ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
     const int size = ci->size;
-    const uint2 *seg = a.members + (size_t)f * N + ci->offset;
+    const uint32_t *sbits = a.mbits + (size_t)f * N + ci->offset;   // ||v|| bits of the members ...
+    const uint32_t *spix = a.mpix + (size_t)f * N + ci->offset;     // ... and their pixel indices
     // ---- scan 1: value range ----
     uint32_t mn = 0xffffffffu, mx = 0u;
     for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
       uint32_t v[kMedBatch];
 #pragma unroll
-      for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? seg[i].x : 0xffffffffu; }
+      for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? sbits[i] : 0xffffffffu; }
 #pragma unroll
       for (int u = 0; u < kMedBatch; u++) if (v[u] != 0xffffffffu) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
     }
@@ -745,12 +756,12 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     if (lane == 0) { s_red[0][wv] = mn; s_red[1][wv] = mx; }
     __syncthreads();
     if (tid == 0) {
-      uint32_t lo = 0xffffffffu, hi = 0u;
-      for (int i = 0; i < kMedThreads / 64; i++) { lo = s_red[0][i] < lo ? s_red[0][i] : lo; hi = s_red[1][i] > hi ? s_red[1][i] : hi; }
-      s_lo = lo; s_hi = hi; s_rem = (uint32_t)(size / 2);
+      uint32_t l0 = 0xffffffffu, h0 = 0u;
+      for (int i = 0; i < kMedThreads / 64; i++) { l0 = s_red[0][i] < l0 ? s_red[0][i] : l0; h0 = s_red[1][i] > h0 ? s_red[1][i] : h0; }
+      s_lo = l0; s_hi = h0;
     }
     __syncthreads();
-    uint32_t lo = s_lo, hi = s_hi, rem = s_rem;
+    uint32_t lo = s_lo, hi = s_hi, rem = (uint32_t)(size / 2);
     bool exact = false;                      // the live range is a single value: every member of it ties
     bool in_lds = false;                     // the live range has been copied to `cand`
     int cn = 0;
@@ -766,7 +777,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
         for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
           uint32_t v[kMedBatch];
 #pragma unroll
-          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? seg[i].x : 0xffffffffu; }
+          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? sbits[i] : 0xffffffffu; }
 #pragma unroll
           for (int u = 0; u < kMedBatch; u++) if (v[u] >= lo && v[u] <= hi) atomicAdd(&hist[(v[u] - lo) >> shift], 1u);
         }
@@ -804,7 +815,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
         for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
           uint2 v[kMedBatch];
 #pragma unroll
-          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? seg[i] : make_uint2(0xffffffffu, 0u); }
+          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? make_uint2(sbits[i], spix[i]) : make_uint2(0xffffffffu, 0u); }
 #pragma unroll
           for (int u = 0; u < kMedBatch; u++)
             if (v[u].x >= lo && v[u].x <= hi) { const uint32_t slot = atomicAdd(&s_cnt, 1u); cand[slot] = v[u]; }
@@ -842,7 +853,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     const bool from_lds = in_lds;
     const int tn = from_lds ? cn : size;
     for (int i = tid; i < tn; i += kMedThreads) {
-      const uint2 m = from_lds ? cand[i] : seg[i];
+      const uint2 m = from_lds ? cand[i] : make_uint2(sbits[i], spix[i]);
       if (m.x == val) {
         const uint32_t px = m.y % (uint32_t)c.W, py = m.y / (uint32_t)c.W;
         atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | m.y);
@@ -850,10 +861,10 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     }
     __syncthreads();
     uint32_t best = (uint32_t)(s_best & 0xffffffffull);
-    if (s_best == ~0ull) best = seg[0].y;            // unreachable for consistent input; keeps every access in bounds
+    if (s_best == ~0ull) best = spix[0];            // unreachable for consistent input; keeps every access in bounds
     const float bvx = a.vx[(size_t)f * N + best], bvy = a.vy[(size_t)f * N + best], bvz = a.vz[(size_t)f * N + best];
     for (int i = tid; i < tn; i += kMedThreads) {
-      const uint2 m = from_lds ? cand[i] : seg[i];
+      const uint2 m = from_lds ? cand[i] : make_uint2(sbits[i], spix[i]);
       if (m.x == val && m.y != best) {
         const size_t q = (size_t)f * N + m.y;
         if (__float_as_uint(a.vx[q]) != __float_as_uint(bvx) || __float_as_uint(a.vy[q]) != __float_as_uint(bvy) ||

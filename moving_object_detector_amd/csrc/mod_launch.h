@@ -18,12 +18,13 @@ struct ClArgs {
   const uint64_t *mask;       // [F][H][mask_words] dynamic bits
   uint64_t *lroot;            // [F][H][mask_words] pixel is the root of a tile-local component (owns a partial record)
   int32_t *parent;            // [F][N] union-find parents (only dynamic entries are ever touched)
-  int32_t *rootlist;          // [F][N] pixel indices of the final roots (aliases `members`, dead before k_relabel)
+  int32_t *rootlist;          // [F][N] pixel indices of the final roots (aliases `mpix`, dead before k_final)
   int32_t *labels;            // [F][N] output plane; used as the root/code plane in between
   CompRec *comps;             // [F][N] statistics records, indexed by the root's pixel index (sparsely touched)
   int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects, 3 overflow flags
   ClusterInfo *clusters;      // [F][max_objects]
-  uint2 *members;             // [F][N] (norm bits, pixel index), grouped per cluster
+  uint32_t *mbits;            // [F][N] ||v|| bit patterns of the members, grouped per cluster (SoA with mpix)
+  uint32_t *mpix;             // [F][N] pixel index of each member
   int32_t *cursors;           // [F][max_objects] fill cursors of the member segments
   void *objects;              // [F][max_objects] ModObject
   int32_t *n_objects;         // [F]

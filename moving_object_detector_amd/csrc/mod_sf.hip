@@ -24,7 +24,7 @@ struct Buffers {
   CompRec *comps = nullptr;
   int32_t *counters = nullptr;
   ClusterInfo *clusters = nullptr;          // 2 x [maxF][max_objects]
-  uint2 *members = nullptr;
+  uint32_t *mbits = nullptr, *mpix = nullptr;
   int32_t *cursors = nullptr;
   unsigned long long *dbg = nullptr;
   uint2 *requests = nullptr;
@@ -209,9 +209,9 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster outputs labels, objects, n_objects are required");
   ClArgs a;
   a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
-  a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.members;
+  a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.mpix;
   a.labels = out->labels; a.comps = c->b.comps; a.counters = c->b.counters; a.clusters = c->b.clusters;
-  a.members = c->b.members; a.cursors = c->b.cursors; a.objects = out->objects; a.n_objects = out->n_objects;
+  a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.cursors = c->b.cursors; a.objects = out->objects; a.n_objects = out->n_objects;
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
   a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
   {
@@ -265,7 +265,8 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   ok &= dalloc(&c->b.comps, (size_t)F * N) == hipSuccess;   // 32 B per pixel of address space, touched only at roots
   ok &= dalloc(&c->b.counters, (size_t)F * 8) == hipSuccess;
   ok &= dalloc(&c->b.clusters, (size_t)2 * F * c->max_objects) == hipSuccess;
-  ok &= dalloc(&c->b.members, (size_t)F * N) == hipSuccess;
+  ok &= dalloc(&c->b.mbits, (size_t)F * N) == hipSuccess;
+  ok &= dalloc(&c->b.mpix, (size_t)F * N) == hipSuccess;
   ok &= dalloc(&c->b.cursors, (size_t)F * c->max_objects) == hipSuccess;
   {
     const size_t tiles = (size_t)c->max_mask_words * ((cfg->max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
@@ -287,7 +288,7 @@ void mod_destroy(ModContext *c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
-  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.comps, b.counters, b.clusters, b.members,
+  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.comps, b.counters, b.clusters, b.mbits, b.mpix,
                  b.cursors, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
@@ -530,7 +531,7 @@ int mod_memcpy_d2h(ModContext *c, void *h, const void *d, uint64_t bytes) {
 // diagnostic: copy an internal buffer to the host (0 members, 1 clusters, 2 counters, 3 cursors)
 int mod_debug_read(ModContext *c, int which, void *dst, unsigned long long bytes) {
   if (!c || !dst) return MOD_ERR_INVALID_ARGUMENT;
-  const void *src = which == 0 ? (const void *)c->b.members : which == 1 ? (const void *)c->b.clusters
+  const void *src = which == 0 ? (const void *)c->b.mbits : which == 4 ? (const void *)c->b.mpix : which == 1 ? (const void *)c->b.clusters
                   : which == 2 ? (const void *)c->b.counters : (const void *)c->b.cursors;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));

@@ -14,7 +14,7 @@ ctx.process(b,ws); ctx.synchronize()
 lib=ctx.lib
 lib.mod_debug_read.argtypes=[C.c_void_p,C.c_int,C.c_void_p,C.c_uint64]
 N=W*H
-mem=np.zeros((N,2),np.uint32); lib.mod_debug_read(ctx.h,0,mem.ctypes.data,mem.nbytes)
+mb=np.zeros(N,np.uint32); lib.mod_debug_read(ctx.h,0,mb.ctypes.data,mb.nbytes); mp=np.zeros(N,np.uint32); lib.mod_debug_read(ctx.h,4,mp.ctypes.data,mp.nbytes); mem=np.stack([mb,mp],1)
 cl=np.zeros((16,8),np.int32); lib.mod_debug_read(ctx.h,1,cl.ctypes.data,cl.nbytes)
 cur=np.zeros(16,np.int32); lib.mod_debug_read(ctx.h,3,cur.ctypes.data,cur.nbytes)
 labels=ws["labels"][0].cpu().numpy()
