@@ -30,7 +30,7 @@ struct DevCam {
 struct FrameConst {
   double m[12];
   double dt;
-  double pad[3];
+  double pad[3];           // pad[0]: |coordinate| bound below which the transformed point is certainly finite (0 = never)
 };
 
 // Per-component record (32 bytes).  Filled by the stats kernel with wave-aggregated atomics.

@@ -3,6 +3,7 @@
 #include "../../include/mod_sf.h"
 #include "mod_launch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -164,7 +165,20 @@ int upload_frame_consts(ModContext *c, const ModFrameBatch *in) {
   for (int f = 0; f < in->frames; f++) {
     transform_to_rows(in->transforms[f], h[f].m);
     h[f].dt = in->dt[f];
-    h[f].pad[0] = h[f].pad[1] = h[f].pad[2] = 0.0;
+    {
+      // |t_i + (m_i0 x + (m_i1 y + m_i2 z))| <= tmax + 3 mmax B stays below FLT_MAX / 2 (so the F32 cast is finite, and no
+      // intermediate can overflow or turn NaN) for every |x|,|y|,|z| <= B.  Non-finite transforms get B = 0: always compute.
+      double mmax = 0.0, tmax = 0.0;
+      bool finite = true;
+      for (int i = 0; i < 12; i++) {
+        const double v = std::fabs(h[f].m[i]);
+        finite = finite && std::isfinite(v);
+        if (i % 4 == 3) tmax = std::max(tmax, v); else mmax = std::max(mmax, v);
+      }
+      double B = 0.0;
+      if (finite && tmax < 1e37) B = std::min((1.7e38 - tmax) / (3.0 * std::max(mmax, 1e-30)), 1e30);
+      h[f].pad[0] = B; h[f].pad[1] = h[f].pad[2] = 0.0;
+    }
   }
   HIP_TRY(c, hipMemcpyAsync(c->b.fc, h, sizeof(FrameConst) * in->frames, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->pinned_ev[slot], c->stream));

@@ -98,8 +98,16 @@ __device__ __forceinline__ void sf_stage1(const DevCam &c, const FrameConst &fc,
 }
 
 //   dpw = disparity_prev at the warp target, rpx / rpy = F64 rays of its column / row
-__device__ __forceinline__ void sf_stage2(const DevCam &c, const FrameConst &fc, const PxState &st, float dpw, double rpx,
-                                          double rpy, Px &o) {
+// The residual test only needs the static flow of stage 1; when it says "static" the velocity is 0 as long as the previous
+// point is valid, and validity (x neither NaN nor inf after the rigid transform) is certain whenever the untransformed
+// point is within FrameConst.pad[0] (a bound derived from the transform on the host).  Stage 2a settles those pixels;
+// only moving pixels and extreme coordinates go on to stage 2b (second rigid transform + velocity), which the kernels
+// guard with a wave-uniform branch — most waves of a street scene skip it entirely.
+struct PxWarp { float Xp, Yp, zp; bool todo, moving; };
+
+__device__ __forceinline__ void sf_stage2a(const DevCam &c, const FrameConst &fc, const PxState &st, float dpw, double rpx,
+                                           double rpy, Px &o, PxWarp &wp) {
+  wp.todo = false; wp.moving = false; wp.Xp = wp.Yp = wp.zp = 0.0f;
   if (!st.go) return;
   if (!disp_in_range(c, dpw)) return;                       // getRightPoint(previous): getDisparity ...
   if (isnan(dpw) || isinf(dpw) || dpw < 0.0f) return;       // ... then NaN / inf / negative
@@ -108,16 +116,27 @@ __device__ __forceinline__ void sf_stage2(const DevCam &c, const FrameConst &fc,
   const float Xp = (float)(rpx * (double)zp);
   const float Yp = (float)(rpy * (double)zp);
   if (isnan(Xp)) return;                                    // NaN passes through the transform untouched -> invalid
-  float tx, ty, tz;
-  iso_apply(fc, Xp, Yp, zp, tx, ty, tz);
-  if (isnan(tx) || isinf(tx)) return;
-
-  // ---- residual test and velocity (scene_flow_constructor.cpp:196-209) ----
+  // ---- residual test (scene_flow_constructor.cpp:196-198) ----
   const float r0 = st.f0 - o.s0, r1 = st.f1 - o.s1;
   float acc = 0.0f;
   acc = acc + r0 * r0;
   acc = acc + r1 * r1;
-  if (sqrtf(acc) >= c.flow_th) {
+  const bool moving = sqrtf(acc) >= c.flow_th;
+  const float safe = (float)fc.pad[0];
+  if (!moving && fabsf(Xp) <= safe && fabsf(Yp) <= safe && fabsf(zp) <= safe) {
+    o.vx = 0.0f; o.vy = 0.0f; o.vz = 0.0f;                  // the transformed point is certainly finite: valid, static
+    o.dyn = 0.0f >= c.speed_th;
+    return;
+  }
+  wp.Xp = Xp; wp.Yp = Yp; wp.zp = zp; wp.todo = true; wp.moving = moving;
+}
+
+__device__ __forceinline__ void sf_stage2b(const DevCam &c, const FrameConst &fc, const PxState &st, const PxWarp &wp, Px &o) {
+  if (!wp.todo) return;
+  float tx, ty, tz;
+  iso_apply(fc, wp.Xp, wp.Yp, wp.zp, tx, ty, tz);
+  if (isnan(tx) || isinf(tx)) return;
+  if (wp.moving) {                                          // velocity (scene_flow_constructor.cpp:200-202)
     o.vx = (float)((double)(st.Xn - tx) / fc.dt);
     o.vy = (float)((double)(st.Yn - ty) / fc.dt);
     o.vz = (float)((double)(st.zn - tz) / fc.dt);
@@ -133,7 +152,9 @@ __device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, 
                                          float dn, float dpo, float f0, float f1, double rx, double ry, Px &o) {
   PxState st;
   sf_stage1(c, fc, x, y, dn, dpo, f0, f1, rx, ry, o, st);
-  sf_stage2(c, fc, st, dprev[(size_t)st.py * c.W + st.px], c.rayx[st.px], c.rayy[st.py], o);
+  PxWarp wp;
+  sf_stage2a(c, fc, st, dprev[(size_t)st.py * c.W + st.px], c.rayx[st.px], c.rayy[st.py], o, wp);
+  if (__any(wp.todo)) sf_stage2b(c, fc, st, wp, o);
 }
 
 // OR-combine the 4-bit nibbles of 16 consecutive lanes into one 64-bit word (lane 16k -> word k of the wave).
@@ -177,10 +198,17 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     const float g2 = dprev_f[(size_t)s2.py * c.W + s2.px], g3 = dprev_f[(size_t)s3.py * c.W + s3.px];
     const double ax0 = c.rayx[s0.px], ax1 = c.rayx[s1.px], ax2 = c.rayx[s2.px], ax3 = c.rayx[s3.px];
     const double ay0 = c.rayy[s0.py], ay1 = c.rayy[s1.py], ay2 = c.rayy[s2.py], ay3 = c.rayy[s3.py];
-    sf_stage2(c, fc, s0, g0, ax0, ay0, p0);
-    sf_stage2(c, fc, s1, g1, ax1, ay1, p1);
-    sf_stage2(c, fc, s2, g2, ax2, ay2, p2);
-    sf_stage2(c, fc, s3, g3, ax3, ay3, p3);
+    PxWarp w0, w1, w2, w3;
+    sf_stage2a(c, fc, s0, g0, ax0, ay0, p0, w0);
+    sf_stage2a(c, fc, s1, g1, ax1, ay1, p1, w1);
+    sf_stage2a(c, fc, s2, g2, ax2, ay2, p2, w2);
+    sf_stage2a(c, fc, s3, g3, ax3, ay3, p3, w3);
+    if (__any(w0.todo || w1.todo || w2.todo || w3.todo)) {   // wave-uniform: some pixel moves (or has extreme coordinates)
+      sf_stage2b(c, fc, s0, w0, p0);
+      sf_stage2b(c, fc, s1, w1, p1);
+      sf_stage2b(c, fc, s2, w2, p2);
+      sf_stage2b(c, fc, s3, w3, p3);
+    }
     *reinterpret_cast<float4 *>(a.x + base) = make_float4(p0.x, p1.x, p2.x, p3.x);
     *reinterpret_cast<float4 *>(a.y + base) = make_float4(p0.y, p1.y, p2.y, p3.y);
     *reinterpret_cast<float4 *>(a.z + base) = make_float4(p0.z, p1.z, p2.z, p3.z);
