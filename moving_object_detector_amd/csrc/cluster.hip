@@ -352,12 +352,19 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
       const uint32_t hmask = (qg < NMAX) ? ~0u : ((lane < 31) ? ~((2u << lane) - 1u) : 0u);
       bool need_any = (vmask & dmask & ~hmask) != 0;
       const uint32_t hv = vmask & hmask;
+      int hold[NMAX + 1];                            // interior label a halo cell hung under before this pixel hooked it
+#pragma unroll
+      for (int k = 0; k <= NMAX; k++) hold[k] = -1;
       if (__ballot(hv != 0)) {
         // hook the halo cell straight under this pixel's label — one LDS atomic instead of a find/unite through the halo
-        // node; if it already hung under another interior label, those two sets must meet (pass 2)
+        // node; if it already hung under another interior label, THAT label's set and this pixel's must meet (pass 2):
+        // the displaced value is the only remaining trace of the older link
 #pragma unroll
         for (int k = 0; k <= NMAX; k++) {
-          if ((hv >> k) & 1u) { const int old = atomicMin(&Lt[base - k], cur); need_any = need_any || (old < kHaloBit && old != cur); }
+          if ((hv >> k) & 1u) {
+            const int old = atomicMin(&Lt[base - k], cur);
+            if (old < kHaloBit && old != cur) { hold[k] = old; need_any = true; }
+          }
         }
       }
       up = up || (vmask != 0);
@@ -367,8 +374,9 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
 #pragma unroll
         for (int k = 0; k <= NMAX; k++) {
           if (k > n || (dv == 0 && k == 0)) continue;
-          const int lab = ld_relaxed(&Lt[base - k]);
-          const bool need = ((vmask >> k) & 1u) && lab != cur && lab != last;
+          const bool ishalo = (hmask >> k) & 1u;
+          const int lab = ishalo ? hold[k] : ld_relaxed(&Lt[base - k]);
+          const bool need = ((vmask >> k) & 1u) && lab >= 0 && lab != cur && lab != last;
           if (__ballot(need)) { COUNT(12, 1) wave_unite_lds(Lt, need, cur, last, lab, lane); }
         }
       }
@@ -878,6 +886,42 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
       o->velocity[0] = (double)bvx; o->velocity[1] = (double)bvy; o->velocity[2] = (double)bvz;
     }
     __syncthreads();
+    // ---- NaN coordinates among the members (only possible for caller-supplied clouds: the scene-flow stage never marks a
+    // pixel dynamic without finite x,y,z).  pcl::getMinMax3D's dense path folds min_p = min_p.min(pt) in member order
+    // (column-major) with SSE semantics "(a < b) ? a : b": a NaN replaces the running value and the next point replaces
+    // the NaN, i.e. the result is the min / max over the members AFTER the last NaN, or NaN when the last member is NaN.
+    {
+      const CompRec rec = a.comps[(size_t)f * N + ci->comp];
+      bool anynan = false;
+      for (int d = 0; d < 3; d++) anynan = anynan || isnan(ord2f(rec.mn[d])) || isnan(ord2f(rec.mx[d]));
+      if (anynan) {                                  // block-uniform
+        const float *pl[3] = {a.x + (size_t)f * N, a.y + (size_t)f * N, a.z + (size_t)f * N};
+        for (int d = 0; d < 3; d++) {
+          if (tid == 0) { s_cnt = 0u; s_bin = 0xffffffffu; s_rem = 0u; s_val = 0u; }   // last NaN key+1, min, max, survivors
+          __syncthreads();
+          for (int i = tid; i < size; i += kMedThreads) {
+            const uint32_t p = spix[i];
+            if (isnan(pl[d][p])) atomicMax(&s_cnt, (p % (uint32_t)c.W) * (uint32_t)c.H + p / (uint32_t)c.W + 1u);
+          }
+          __syncthreads();
+          const uint32_t lastnan = s_cnt;             // column-major key + 1 of the last NaN member, 0 if none
+          for (int i = tid; i < size; i += kMedThreads) {
+            const uint32_t p = spix[i];
+            const uint32_t key1 = (p % (uint32_t)c.W) * (uint32_t)c.H + p / (uint32_t)c.W + 1u;
+            if (key1 > lastnan) { const uint32_t o = f2ord(pl[d][p]); atomicMin(&s_bin, o); atomicMax(&s_rem, o); atomicAdd(&s_val, 1u); }
+          }
+          __syncthreads();
+          if (tid == 0) {
+            ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
+            const float nanv = __uint_as_float(0x7fc00000u);
+            const float mn = s_val ? ord2f(s_bin) : nanv, mx = s_val ? ord2f(s_rem) : nanv;
+            o->bounding_box[d] = (double)(mx - mn);
+            o->center[d] = (double)((mn + mx) / 2.0f);
+          }
+          __syncthreads();
+        }
+      }
+    }
   }
 }
 

@@ -341,6 +341,10 @@ int mod_set_params(ModContext *c, const ModParams *p) {
   if (p->neighbor_distance < 1 || p->neighbor_distance > MOD_MAX_NEIGHBOR_DISTANCE)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "neighbor_distance must be in 1..16");
   if (p->cluster_size < 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster_size must be >= 1");
+  // at most N / cluster_size clusters can survive the size filter: the object arrays must hold them all, so that no
+  // cluster is ever dropped (the default capacity N/100 covers the reference's whole range cluster_size >= 100)
+  if (c->maxN / (size_t)p->cluster_size > (size_t)c->max_objects)
+    return fail(c, MOD_ERR_CAPACITY, "ModConfig.max_objects is smaller than max_width*max_height / cluster_size");
   {   // link-request scratch grows with neighbor_distance
     const size_t tiles = (size_t)c->max_mask_words * ((c->cfg.max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
     const size_t need = (size_t)c->cfg.max_frames * tiles * ccl_request_capacity(p->neighbor_distance);

@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
 
   ModConfig cfg{};
   cfg.device = 0; cfg.max_width = W; cfg.max_height = H; cfg.max_frames = 1;
+  cfg.max_objects = W * H / (int)prm[1] + 1;   // every cluster that can survive the size filter fits
   ModContext *ctx = nullptr;
   if (mod_create(&cfg, &ctx) != MOD_OK) { fprintf(stderr, "mod_create failed\n"); return 4; }
 

@@ -16,7 +16,7 @@ torch = pytest.importorskip("torch")
 
 def _ctx(cam, prm, frames=1):
     from moving_object_detector_amd.pipeline import Context
-    ctx = Context(cam.width, cam.height, max_frames=frames)
+    ctx = Context(cam.width, cam.height, max_frames=frames, max_objects=cam.width * cam.height // prm.cluster_size + 1)
     ctx.set_camera(cam)
     ctx.set_params(prm)
     return ctx
@@ -29,7 +29,7 @@ def test_device_path_matches_golden(path):
     ws = ctx.workspace(1, aos=True, extras=True)
     dev = ctx.device
     b = ctx.make_batch(torch.from_numpy(g["d_now"][None]).to(dev), torch.from_numpy(g["d_prev"][None]).to(dev),
-                       torch.from_numpy(g["flow"][None]).to(dev), g["t"][None], g["q"][None], [float(g["dt"])])
+                       torch.from_numpy(g["flow"][None]).to(dev), g["t"][None], g["q"][None], [float(np.asarray(g["dt"]).item())])
     assert ctx.process(b, ws) == 0
     ctx.synchronize()
     for i, k in enumerate(PLANES):
@@ -57,7 +57,7 @@ def test_host_entry_points_match_golden(path):
     n = C.c_int32(-1)
     tf = capi.transforms_array([g["t"]], [g["q"]])
     rc = ctx.lib.mod_process_frame_host(ctx.h, g["d_now"].ctypes.data, g["d_prev"].ctypes.data, g["flow"].ctypes.data, tf,
-                                        float(g["dt"]), cloud.ctypes.data, labels.ctypes.data, objs.ctypes.data, 64, C.byref(n))
+                                        float(np.asarray(g["dt"]).item()), cloud.ctypes.data, labels.ctypes.data, objs.ctypes.data, 64, C.byref(n))
     assert rc == 0
     for j, k in zip((0, 1, 2, 4, 5, 6), PLANES):
         assert bits_equal(cloud[..., j], g[k]), k
@@ -108,4 +108,7 @@ def test_configuration_errors():
         ctx.set_params(synth.Params(neighbor_distance=17))
     with pytest.raises(capi.ModError):
         ctx.set_params(synth.Params(cluster_size=0))
+    with pytest.raises(capi.ModError) as e:
+        ctx.set_params(synth.Params(cluster_size=10))      # 64*48/10 clusters could survive, capacity is 64*48/100
+    assert e.value.code == capi.MOD_ERR_CAPACITY
     ctx.close()

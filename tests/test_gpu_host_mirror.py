@@ -24,14 +24,14 @@ def test_host_mirror_matches_golden(path, tmp_path):
     np.asarray(g["prm"], np.float64).tofile(d + "/prm.f64")
     for k in ("d_now", "d_prev", "flow"):
         np.ascontiguousarray(g[k], np.float32).tofile(f"{d}/{k}.f32")
-    np.concatenate([g["t"], g["q"], [float(g["dt"])]]).astype(np.float64).tofile(d + "/tq.f64")
+    np.concatenate([g["t"], g["q"], [float(np.asarray(g["dt"]).item())]]).astype(np.float64).tofile(d + "/tq.f64")
     r = subprocess.run([EXE, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     H, W = g["d_now"].shape
     cloud = np.fromfile(d + "/cloud.bin", np.float32).reshape(H, W, 8)
     # dt reaches the library as (100 + dt) - 100: only exact when that round trip is; the fixtures use dt = 0.1
-    dt_seen = (100.0 + float(g["dt"])) - 100.0
-    if dt_seen == float(g["dt"]):
+    dt_seen = (100.0 + float(np.asarray(g["dt"]).item())) - 100.0
+    if dt_seen == float(np.asarray(g["dt"]).item()):
         for j, k in zip((0, 1, 2, 4, 5, 6), PLANES):
             assert bits_equal(cloud[..., j], g[k]), k
     else:

@@ -15,7 +15,7 @@ torch = pytest.importorskip("torch")
 def _run_gpu(cam, prm, batch, aos=False, extras=False, fused=True):
     from moving_object_detector_amd.pipeline import Context
     F, H, W = batch["disparity_now"].shape
-    ctx = Context(W, H, max_frames=F)
+    ctx = Context(W, H, max_frames=F, max_objects=max(W * H // 100, W * H // prm.cluster_size + 1))
     ctx.set_camera(cam)
     ctx.set_params(prm)
     ws = ctx.workspace(F, aos=aos, extras=extras)
