@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU (bounded sample)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--share-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -99,12 +101,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend)
 
     from moving_object_detector_amd import capi, synth
     from moving_object_detector_amd import dist as mdist
@@ -117,7 +124,7 @@ def main():
     if rank == 0:
         cam_s = capi.camera_struct(synth.make_camera(W, H))
         prm_s = capi.params_struct(synth.Params())
-    cam_s, prm_s = mdist.broadcast_config(cam_s, prm_s, src=0, device=dev)
+    cam_s, prm_s = mdist.broadcast_config(cam_s, prm_s, src=0, device=dev if args.backend == "nccl" else None)
 
     # synthetic pairs of this rank's shard (distinct seeds per rank), tiled to F frames at distinct HBM addresses
     cam, host = synth.make_batch(W, H, G, seed=0, first_frame=rank * G)
@@ -153,7 +160,7 @@ def main():
     stage = [ctx.stage_time(i) for i in range(capi.MOD_STAGE_COUNT)]
     ctx.set_profiling(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -22,6 +22,7 @@
 //   k_select      size filter + ordering by first_edge_key (the reference's numbering) + bbox/centre.
 //   k_relabel     final labels + per-cluster member segments; k_median: radix select of the median-||v|| member.
 #include "mod_launch.h"
+#include "introsort_emul.h"
 #include "../../include/mod_sf.h"
 
 #pragma clang fp contract(off)
@@ -925,6 +926,136 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
   }
 }
 
+// Tied medians, exactly.  When k_median flagged a cluster (members tie on ||v|| with different vectors), the member that
+// libstdc++'s std::sort leaves at size/2 is found by replaying introsort's moves on the sub-range that holds that position
+// (introsort_emul.h): the members are laid out in the reference's initial order (column-major pixel order,
+// clusterMap2IndicesCluster, clusterer_nodelet.cpp:97-117), each __unguarded_partition is done by the whole workgroup —
+// its k-th swap exchanges the k-th element from the left that is not before the pivot with the k-th from the right that is
+// not after it, so ranks from two prefix counts give every swap at once — and the finished (<= 16 element) range gets the
+// stable insertion sort.  Rare path: one workgroup per flagged cluster, nothing to do for the others.
+// Scratch (all dead by now): keys -> parent plane, pixels -> comps region, swap lists -> the member arrays.
+constexpr int kTieThreads = 1024, kTieCols = 2048;
+
+__global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a) {
+  using namespace introsort_emul;
+  const int f = blockIdx.y, tid = threadIdx.x;
+  const size_t N = (size_t)c.W * c.H, fN = (size_t)f * N;
+  const int K = a.counters[f * 8 + 1];
+  __shared__ int colcnt[kTieCols];
+  __shared__ int s_cntA[kTieThreads], s_cntB[kTieThreads];
+  __shared__ int s_xmin, s_xmax, s_ymin, s_ymax, s_first, s_last, s_depth, s_m, s_totA, s_done;
+  __shared__ uint32_t s_answer;
+  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+    ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
+    if (ci->ambiguous != 1) continue;                // block-uniform
+    const int size = ci->size, off = ci->offset;
+    uint32_t *key = (uint32_t *)(a.parent + fN) + off;
+    uint32_t *val = (uint32_t *)(a.comps + fN) + off;
+    uint32_t *Apos = a.mbits + fN + off, *Bpos = a.mpix + fN + off;
+    // ---- image-space bounding box of the cluster (from its member list, before that list becomes scratch) ----
+    if (tid == 0) { s_xmin = 0x7fffffff; s_ymin = 0x7fffffff; s_xmax = -1; s_ymax = -1; }
+    __syncthreads();
+    for (int i = tid; i < size; i += kTieThreads) {
+      const int p = (int)Bpos[i], x = p % c.W, y = p / c.W;
+      atomicMin(&s_xmin, x); atomicMax(&s_xmax, x); atomicMin(&s_ymin, y); atomicMax(&s_ymax, y);
+    }
+    __syncthreads();
+    const int xmin = s_xmin, ymin = s_ymin, ymax = s_ymax, ncols = s_xmax - xmin + 1;
+    if (ncols > kTieCols) continue;                  // wider than the column table: keep the canonical pick (stays flagged)
+    // ---- members in column-major order: count per column, prefix, fill ----
+    const int *lab = a.labels + fN;
+    for (int ci_ = tid; ci_ < ncols; ci_ += kTieThreads) {
+      int cnt = 0;
+      for (int y = ymin; y <= ymax; y++) cnt += lab[(size_t)y * c.W + xmin + ci_] == k;
+      colcnt[ci_] = cnt;
+    }
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int i = 0; i < ncols; i++) { const int t = colcnt[i]; colcnt[i] = run; run += t; } }
+    __syncthreads();
+    for (int ci_ = tid; ci_ < ncols; ci_ += kTieThreads) {
+      int slot = colcnt[ci_];
+      for (int y = ymin; y <= ymax; y++) {
+        const int p = y * c.W + xmin + ci_;
+        if (lab[p] == k) {
+          key[slot] = __float_as_uint(norm3_f32(a.vx[fN + p], a.vy[fN + p], a.vz[fN + p]));
+          val[slot] = (uint32_t)p;
+          slot++;
+        }
+      }
+    }
+    if (tid == 0) { s_first = 0; s_last = size; s_depth = 2 * floor_log2(size); s_done = 0; }
+    __syncthreads();
+    // ---- introsort, only along the range that holds position size/2 ----
+    const View v{key, val};
+    const int want = size / 2;
+    while (true) {
+      const int first = s_first, last = s_last;
+      if (last - first <= 16) break;
+      if (s_depth == 0) {                            // depth limit hit: __partial_sort(first, last, last) = heap sort
+        __syncthreads();
+        if (tid == 0) { heap_sort(v, first, last); s_answer = val[want]; s_done = 1; }
+        __syncthreads();
+        break;
+      }
+      __syncthreads();
+      if (tid == 0) { s_depth--; move_median_to_first(v, first, first + 1, first + (last - first) / 2, last - 1); }
+      __syncthreads();
+      const uint32_t pk = key[first];
+      const int lo = first + 1, L = last - lo, chunk = (L + kTieThreads - 1) / kTieThreads;
+      const int b0 = min(lo + tid * chunk, last), b1 = min(b0 + chunk, last);
+      // A: elements NOT before the pivot (key <= pk), counted from the left; B: elements NOT after it (key >= pk), from the right
+      int cntA = 0, cntB = 0;
+      for (int j = b0; j < b1; j++) { const uint32_t kj = key[j]; cntA += kj <= pk; cntB += kj >= pk; }
+      s_cntA[tid] = cntA; s_cntB[tid] = cntB;
+      __syncthreads();
+      if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < kTieThreads; t++) { const int x = s_cntA[t]; s_cntA[t] = run; run += x; }
+        s_totA = run; run = 0;
+        for (int t = kTieThreads - 1; t >= 0; t--) { const int x = s_cntB[t]; s_cntB[t] = run; run += x; }
+        s_m = 0;
+      }
+      __syncthreads();
+      {
+        int iA = s_cntA[tid], seenB = 0, mloc = 0;
+        const int sufB = s_cntB[tid];
+        for (int j = b0; j < b1; j++) {
+          const uint32_t kj = key[j];
+          const bool le = kj <= pk, ge = kj >= pk;
+          if (ge) seenB++;
+          const int geR = sufB + (cntB - seenB);     // elements of B strictly right of j
+          if (le) { Apos[iA] = (uint32_t)j; mloc += (geR >= iA + 1); iA++; }   // the iA-th stop of the left pointer swaps iff the iA-th stop of the right pointer lies right of it
+          if (ge) Bpos[geR] = (uint32_t)j;
+        }
+        if (mloc) atomicAdd(&s_m, mloc);
+      }
+      __syncthreads();
+      const int m = s_m;
+      for (int i = tid; i < m; i += kTieThreads) v.swap((int)Apos[i], (int)Bpos[i]);
+      __syncthreads();
+      if (tid == 0) {
+        // the left pointer's final stop: the next untouched element of A, unless the right pointer's last swap partner comes first
+        const int am = (m < s_totA) ? (int)Apos[m] : 0x7fffffff, bm = (m > 0) ? (int)Bpos[m - 1] : 0x7fffffff;
+        const int cut = am < bm ? am : bm;
+        if (want >= cut) s_first = cut; else s_last = cut;
+      }
+      __syncthreads();
+    }
+    if (!s_done) {
+      __syncthreads();
+      if (tid == 0) { insertion_sort(v, s_first, s_last); s_answer = val[want]; }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const uint32_t best = s_answer;
+      ci->med_pix = (int)best; ci->ambiguous = 2;    // 2 = tie resolved by replaying the reference's sort
+      ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
+      o->velocity[0] = (double)a.vx[fN + best]; o->velocity[1] = (double)a.vy[fN + best]; o->velocity[2] = (double)a.vz[fN + best];
+    }
+    __syncthreads();
+  }
+}
+
 // publishMovingObjects (clusterer_nodelet.cpp:324-343): ids run over ACCEPTED clusters only; a cluster is rejected when
 // (double)||median v|| < dynamic_speed (:176) — unreachable for members that are all dynamic, kept for exactness.
 __global__ void k_finalize(DevCam c, ClArgs a, int frames) {
@@ -973,6 +1104,7 @@ void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
 }
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   hipLaunchKernelGGL(k_median, dim3(16, frames), dim3(kMedThreads), 0, s, c, a);
+  hipLaunchKernelGGL(k_median_ties, dim3(4, frames), dim3(kTieThreads), 0, s, c, a);
   hipLaunchKernelGGL(k_finalize, dim3((frames + 63) / 64), dim3(64), 0, s, c, a, frames);
 }
 

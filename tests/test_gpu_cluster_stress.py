@@ -43,7 +43,7 @@ def _check(oracle, planes, prm, W, H):
     rl, ro, rK = oracle.cluster(planes, prm, "tidy", max_objects=W * H // 2 + 16)
     assert K == rK, (K, rK)
     assert np.array_equal(lab, rl), int((lab != rl).sum())
-    compare_objects(objs, ro, strict_velocity=False)
+    compare_objects(objs, ro, strict_velocity=True)
 
 
 @pytest.mark.parametrize("density", [0.02, 0.2, 0.5, 0.9])
@@ -116,5 +116,5 @@ def test_batch_of_frames_with_different_content(oracle):
     for f, cl in enumerate(clouds):
         rl, ro, rK = oracle.cluster(cl, prm, "tidy", max_objects=W * H)
         assert np.array_equal(labels[f], rl), f
-        compare_objects(objs[f], ro, strict_velocity=False)
+        compare_objects(objs[f], ro, strict_velocity=True)
     ctx.close()

@@ -44,7 +44,7 @@ def _run_gpu(cam, prm, batch, aos=False, extras=False, fused=True):
     return out
 
 
-def _check_against_oracle(oracle, cam, prm, batch, out, strict_velocity=False):
+def _check_against_oracle(oracle, cam, prm, batch, out, strict_velocity=True):
     F = batch["disparity_now"].shape[0]
     for f in range(F):
         ref = oracle.construct(cam, prm, batch["disparity_now"][f], batch["disparity_prev"][f], batch["flow"][f],
