@@ -934,120 +934,264 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
 // not after it, so ranks from two prefix counts give every swap at once — and the finished (<= 16 element) range gets the
 // stable insertion sort.  Rare path: one workgroup per flagged cluster, nothing to do for the others.
 // Scratch (all dead by now): keys -> parent plane, pixels -> comps region, swap lists -> the member arrays.
-constexpr int kTieThreads = 1024, kTieCols = 2048;
+constexpr int kTieThreads = 1024, kTieCols = 2048, kTieLds = 8192;
+
+struct TieShared {           // control block of one workgroup of k_median_ties
+  int cntA[kTieThreads / 64], cntB[kTieThreads / 64];
+  int first, last, depth, m, totA, done;
+  uint32_t answer;
+};
+
+// One __unguarded_partition_pivot step on [first, last) of (key, val), by the whole workgroup; updates sh.first / sh.last
+// to the side that holds `want`.  Works on HBM or LDS arrays alike (KP is deduced per call site, so each instance keeps its
+// address space).  All threads must call it; ends with a barrier.
+template <class KP, class PP>
+__device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP Bpos, int first, int last, int want, TieShared &sh,
+                                                   int tid) {
+  using namespace introsort_emul;
+  const int lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = kTieThreads / 64;
+  if (tid == 0) {
+    sh.depth--;
+    const View v{&key[0], &val[0]};
+    move_median_to_first(v, first, first + 1, first + (last - first) / 2, last - 1);
+  }
+  __syncthreads();
+  const uint32_t pk = key[first];
+  // A: elements NOT before the pivot (key <= pk), ranked from the left; B: elements NOT after it (key >= pk), ranked from the
+  // right.  Wave w owns one contiguous slice and reads it 64 consecutive elements at a time (4 reads in flight).
+  const int lo = first + 1, L = last - lo;
+  const int slice = (((L + NW - 1) / NW) + 63) & ~63;          // a multiple of 64: a wave's 64-element reads never straddle slices
+  const int w0 = min(lo + wv * slice, last), w1 = min(w0 + slice, last);
+  int cntA = 0, cntB = 0;
+  for (int j0 = w0; j0 < w1; j0 += 512) {
+    uint32_t k4[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int j = j0 + u * 64 + lane; k4[u] = (j < w1) ? key[j] : 0u; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const bool in = j0 + u * 64 + lane < w1;
+      cntA += __popcll((unsigned long long)__ballot(in && k4[u] <= pk));
+      cntB += __popcll((unsigned long long)__ballot(in && k4[u] >= pk));
+    }
+  }
+  if (lane == 0) { sh.cntA[wv] = cntA; sh.cntB[wv] = cntB; }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int t = 0; t < NW; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; }
+    sh.totA = run; run = 0;
+    for (int t = NW - 1; t >= 0; t--) { const int x = sh.cntB[t]; sh.cntB[t] = run; run += x; }
+    sh.m = 0;
+  }
+  __syncthreads();
+  {
+    int runA = sh.cntA[wv], seenB = 0, mloc = 0;
+    const int sufB = sh.cntB[wv];
+    const uint64_t lt = (1ull << lane) - 1ull, le_m = lt | (1ull << lane);
+    for (int j0 = w0; j0 < w1; j0 += 512) {
+      uint32_t k4[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int j = j0 + u * 64 + lane; k4[u] = (j < w1) ? key[j] : 0u; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + u * 64 + lane;
+        const bool in = j < w1, le = in && k4[u] <= pk, ge = in && k4[u] >= pk;
+        const uint64_t bl = __ballot(le), bg = __ballot(ge);
+        const int iA = runA + __popcll((unsigned long long)(bl & lt));
+        // elements of B strictly right of j: later waves' + this wave's not yet seen, minus those up to and including this lane
+        const int geR = sufB + (cntB - seenB - __popcll((unsigned long long)(bg & le_m)));
+        // the iA-th stop of the left pointer swaps iff the iA-th stop of the right pointer lies right of it
+        if (le) { Apos[iA] = j; mloc += (geR >= iA + 1); }
+        if (ge) Bpos[geR] = j;
+        runA += __popcll((unsigned long long)bl);
+        seenB += __popcll((unsigned long long)bg);
+      }
+    }
+    if (mloc) atomicAdd(&sh.m, mloc);
+  }
+  __syncthreads();
+  const int m = sh.m;
+  for (int i0 = tid; i0 < m; i0 += kTieThreads * 2) {           // the m swaps, two per thread in flight
+    const int i1 = i0 + kTieThreads;
+    const int a0 = (int)Apos[i0], b0 = (int)Bpos[i0];
+    const int a1 = (i1 < m) ? (int)Apos[i1] : a0, b1 = (i1 < m) ? (int)Bpos[i1] : b0;
+    const uint32_t ka0 = key[a0], va0 = val[a0], kb0 = key[b0], vb0 = val[b0];
+    const uint32_t ka1 = key[a1], va1 = val[a1], kb1 = key[b1], vb1 = val[b1];
+    key[a0] = kb0; val[a0] = vb0; key[b0] = ka0; val[b0] = va0;
+    if (i1 < m) { key[a1] = kb1; val[a1] = vb1; key[b1] = ka1; val[b1] = va1; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // the left pointer's final stop: the next untouched element of A, unless the right pointer's last swap partner comes first
+    const int am = (m < sh.totA) ? (int)Apos[m] : 0x7fffffff, bm = (m > 0) ? (int)Bpos[m - 1] : 0x7fffffff;
+    const int cut = am < bm ? am : bm;
+    if (want >= cut) sh.first = cut; else sh.last = cut;
+  }
+  __syncthreads();
+}
+
+// Runs partition steps until the live range is at most `stop` elements long (or the depth limit turns it into a heap sort).
+template <class KP, class PP>
+__device__ __forceinline__ void tie_narrow(KP key, KP val, PP Apos, PP Bpos, int want, int stop, TieShared &sh, int tid) {
+  using namespace introsort_emul;
+  while (true) {
+    const int first = sh.first, last = sh.last;
+    if (last - first <= stop || sh.done) break;
+    if (sh.depth == 0) {                             // depth limit hit: __partial_sort(first, last, last) = heap sort
+      __syncthreads();
+      if (tid == 0) { const View v{&key[0], &val[0]}; heap_sort(v, first, last); sh.answer = val[want]; sh.done = 1; }
+      __syncthreads();
+      break;
+    }
+    __syncthreads();
+    tie_partition_step(key, val, Apos, Bpos, first, last, want, sh, tid);
+  }
+}
 
 __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a) {
   using namespace introsort_emul;
-  const int f = blockIdx.y, tid = threadIdx.x;
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t N = (size_t)c.W * c.H, fN = (size_t)f * N;
   const int K = a.counters[f * 8 + 1];
-  __shared__ int colcnt[kTieCols];
-  __shared__ int s_cntA[kTieThreads], s_cntB[kTieThreads];
-  __shared__ int s_xmin, s_xmax, s_ymin, s_ymax, s_first, s_last, s_depth, s_m, s_totA, s_done;
-  __shared__ uint32_t s_answer;
+  __shared__ uint32_t lkey[kTieLds], lval[kTieLds];
+  __shared__ uint16_t lA[kTieLds], lB[kTieLds];      // positions inside the LDS-resident range fit 16 bits
+  __shared__ int s_box[4];
+  __shared__ TieShared sh;
   for (int k = blockIdx.x; k < K; k += gridDim.x) {
     ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
     if (ci->ambiguous != 1) continue;                // block-uniform
+#ifdef MOD_PHASE_COUNTERS
+    unsigned long long tt0 = wall_clock64(), tt1;
+#define TSTAMP(i) { __syncthreads(); tt1 = wall_clock64(); if (tid == 0) atomicAdd(&a.dbg[i], tt1 - tt0); tt0 = tt1; }
+#else
+#define TSTAMP(i)
+#endif
     const int size = ci->size, off = ci->offset;
     uint32_t *key = (uint32_t *)(a.parent + fN) + off;
     uint32_t *val = (uint32_t *)(a.comps + fN) + off;
     uint32_t *Apos = a.mbits + fN + off, *Bpos = a.mpix + fN + off;
     // ---- image-space bounding box of the cluster (from its member list, before that list becomes scratch) ----
-    if (tid == 0) { s_xmin = 0x7fffffff; s_ymin = 0x7fffffff; s_xmax = -1; s_ymax = -1; }
+    if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0; s_box[2] = 0x7fffffff; s_box[3] = 0; }
     __syncthreads();
-    for (int i = tid; i < size; i += kTieThreads) {
-      const int p = (int)Bpos[i], x = p % c.W, y = p / c.W;
-      atomicMin(&s_xmin, x); atomicMax(&s_xmax, x); atomicMin(&s_ymin, y); atomicMax(&s_ymax, y);
+    {
+      uint32_t x0 = 0xffffffffu, x1 = 0, y0 = 0xffffffffu, y1 = 0;
+      const float invW = 1.0f / (float)c.W;          // p < 2^24: (p + 0.5) / W truncates to the row exactly
+      for (int i0 = tid; i0 < size; i0 += kTieThreads * 4) {
+        uint32_t p4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) p4[u] = Bpos[min(i0 + u * kTieThreads, size - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t y = (uint32_t)(((float)p4[u] + 0.5f) * invW), x = p4[u] - y * (uint32_t)c.W;
+          x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
+        }
+      }
+      x0 = wave_min_u32(x0); x1 = wave_max_u32(x1); y0 = wave_min_u32(y0); y1 = wave_max_u32(y1);
+      if (lane == 0 && x0 != 0xffffffffu) { atomicMin(&s_box[0], (int)x0); atomicMax(&s_box[1], (int)x1); atomicMin(&s_box[2], (int)y0); atomicMax(&s_box[3], (int)y1); }
     }
     __syncthreads();
-    const int xmin = s_xmin, ymin = s_ymin, ymax = s_ymax, ncols = s_xmax - xmin + 1;
+    TSTAMP(20)
+    if (c.debug & (1 << 20)) continue;
+    const int xmin = s_box[0], ymin = s_box[2], ymax = s_box[3], ncols = s_box[1] - xmin + 1;
     if (ncols > kTieCols) continue;                  // wider than the column table: keep the canonical pick (stays flagged)
-    // ---- members in column-major order: count per column, prefix, fill ----
+    // ---- members in column-major order: count, prefix, fill.  The bounding box is cut into (64-column chunk, row segment)
+    // work items so that all 16 waves are busy; a wave reads 4 rows of its chunk at a time (coalesced, 4-16 reads in flight).
+    // Counts live in the LDS arrays of the later LDS phase: cc[segment][column] ----
     const int *lab = a.labels + fN;
-    for (int ci_ = tid; ci_ < ncols; ci_ += kTieThreads) {
+    const int nchunks = (ncols + 63) / 64, ncp = nchunks * 64;
+    const int nseg = max(1, min(8, (2 * kTieLds) / ncp));          // lkey + lval hold 2 * kTieLds ints
+    const int rows = ymax - ymin + 1, segH = (rows + nseg - 1) / nseg;
+    int *cc = (int *)&lkey[0];
+    int *cc2 = (int *)&lval[0];
+    auto CC = [&](int sg, int cx) -> int & { const int i = sg * ncp + cx; return i < kTieLds ? cc[i] : cc2[i - kTieLds]; };
+    for (int it = wv; it < nchunks * nseg; it += kTieThreads / 64) {
+      const int ch = it % nchunks, sg = it / nchunks;
+      const int cx = ch * 64 + lane, x = min(xmin + cx, c.W - 1);
+      const int ya = ymin + sg * segH, yb = min(ya + segH - 1, ymax);
       int cnt = 0;
-      for (int y = ymin; y <= ymax; y++) cnt += lab[(size_t)y * c.W + xmin + ci_] == k;
-      colcnt[ci_] = cnt;
+      for (int y0 = ya; y0 <= yb; y0 += 8) {
+        int l8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) l8[u] = lab[(size_t)min(y0 + u, yb) * c.W + x];
+#pragma unroll
+        for (int u = 0; u < 8; u++) cnt += (y0 + u <= yb) && l8[u] == k;
+      }
+      CC(sg, cx) = (cx < ncols) ? cnt : 0;
     }
     __syncthreads();
-    if (tid == 0) { int run = 0; for (int i = 0; i < ncols; i++) { const int t = colcnt[i]; colcnt[i] = run; run += t; } }
-    __syncthreads();
-    for (int ci_ = tid; ci_ < ncols; ci_ += kTieThreads) {
-      int slot = colcnt[ci_];
-      for (int y = ymin; y <= ymax; y++) {
-        const int p = y * c.W + xmin + ci_;
-        if (lab[p] == k) {
-          key[slot] = __float_as_uint(norm3_f32(a.vx[fN + p], a.vy[fN + p], a.vz[fN + p]));
-          val[slot] = (uint32_t)p;
-          slot++;
-        }
+    TSTAMP(21)
+    if (c.debug & (1 << 21)) continue;
+    // exclusive prefix in column-major order: columns left to right, inside a column the segments top to bottom
+    {
+      int tot0 = 0, tot1 = 0;                                        // thread t owns columns 2t and 2t+1
+      const int c0 = 2 * tid, c1 = 2 * tid + 1;
+      for (int sg = 0; sg < nseg; sg++) { if (c0 < ncp) tot0 += CC(sg, c0); if (c1 < ncp) tot1 += CC(sg, c1); }
+      int incl = tot0 + tot1;
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      if (lane == 63) sh.cntA[wv] = incl;
+      __syncthreads();
+      if (tid == 0) { int run = 0; for (int t = 0; t < kTieThreads / 64; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; } }
+      __syncthreads();
+      int start0 = sh.cntA[wv] + incl - tot0 - tot1, start1 = start0 + tot0;
+      for (int sg = 0; sg < nseg; sg++) {
+        if (c0 < ncp) { const int t = CC(sg, c0); CC(sg, c0) = start0; start0 += t; }
+        if (c1 < ncp) { const int t = CC(sg, c1); CC(sg, c1) = start1; start1 += t; }
       }
     }
-    if (tid == 0) { s_first = 0; s_last = size; s_depth = 2 * floor_log2(size); s_done = 0; }
     __syncthreads();
-    // ---- introsort, only along the range that holds position size/2 ----
-    const View v{key, val};
+    for (int it = wv; it < nchunks * nseg; it += kTieThreads / 64) {
+      const int ch = it % nchunks, sg = it / nchunks;
+      const int cx = ch * 64 + lane, x = min(xmin + cx, c.W - 1);
+      const int ya = ymin + sg * segH, yb = min(ya + segH - 1, ymax);
+      int slot = CC(sg, cx);
+      for (int y0 = ya; y0 <= yb; y0 += 8) {          // labels and velocities of 8 rows in flight, all coalesced
+        int l8[8];
+        float vx[8], vy[8], vz[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const size_t q = (size_t)min(y0 + u, yb) * c.W + x;
+          l8[u] = lab[q]; vx[u] = a.vx[fN + q]; vy[u] = a.vy[fN + q]; vz[u] = a.vz[fN + q];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (cx < ncols && y0 + u <= yb && l8[u] == k) {
+            val[slot] = (uint32_t)((y0 + u) * c.W + x);
+            key[slot] = __float_as_uint(norm3_f32(vx[u], vy[u], vz[u]));
+            slot++;
+          }
+      }
+    }
+    __syncthreads();
+    TSTAMP(22)
+    TSTAMP(23)
+    if (c.debug & (1 << 22)) continue;
+    if (tid == 0) { sh.first = 0; sh.last = size; sh.depth = 2 * floor_log2(size); sh.done = 0; }
+    __syncthreads();
+    // ---- introsort, only along the range that holds position size/2: in HBM while the range is long, then in LDS ----
     const int want = size / 2;
-    while (true) {
-      const int first = s_first, last = s_last;
-      if (last - first <= 16) break;
-      if (s_depth == 0) {                            // depth limit hit: __partial_sort(first, last, last) = heap sort
-        __syncthreads();
-        if (tid == 0) { heap_sort(v, first, last); s_answer = val[want]; s_done = 1; }
-        __syncthreads();
-        break;
-      }
+    tie_narrow(key, val, Apos, Bpos, want, kTieLds, sh, tid);
+    TSTAMP(24)
+    if (c.debug & (1 << 23)) continue;
+    __syncthreads();
+    if (!sh.done) {
+      const int first = sh.first, len = sh.last - first;
+      for (int i = tid; i < len; i += kTieThreads) { lkey[i] = key[first + i]; lval[i] = val[first + i]; }
       __syncthreads();
-      if (tid == 0) { s_depth--; move_median_to_first(v, first, first + 1, first + (last - first) / 2, last - 1); }
+      if (tid == 0) { sh.first = 0; sh.last = len; }
       __syncthreads();
-      const uint32_t pk = key[first];
-      const int lo = first + 1, L = last - lo, chunk = (L + kTieThreads - 1) / kTieThreads;
-      const int b0 = min(lo + tid * chunk, last), b1 = min(b0 + chunk, last);
-      // A: elements NOT before the pivot (key <= pk), counted from the left; B: elements NOT after it (key >= pk), from the right
-      int cntA = 0, cntB = 0;
-      for (int j = b0; j < b1; j++) { const uint32_t kj = key[j]; cntA += kj <= pk; cntB += kj >= pk; }
-      s_cntA[tid] = cntA; s_cntB[tid] = cntB;
+      tie_narrow(&lkey[0], &lval[0], &lA[0], &lB[0], want - first, 16, sh, tid);
       __syncthreads();
-      if (tid == 0) {
-        int run = 0;
-        for (int t = 0; t < kTieThreads; t++) { const int x = s_cntA[t]; s_cntA[t] = run; run += x; }
-        s_totA = run; run = 0;
-        for (int t = kTieThreads - 1; t >= 0; t--) { const int x = s_cntB[t]; s_cntB[t] = run; run += x; }
-        s_m = 0;
-      }
-      __syncthreads();
-      {
-        int iA = s_cntA[tid], seenB = 0, mloc = 0;
-        const int sufB = s_cntB[tid];
-        for (int j = b0; j < b1; j++) {
-          const uint32_t kj = key[j];
-          const bool le = kj <= pk, ge = kj >= pk;
-          if (ge) seenB++;
-          const int geR = sufB + (cntB - seenB);     // elements of B strictly right of j
-          if (le) { Apos[iA] = (uint32_t)j; mloc += (geR >= iA + 1); iA++; }   // the iA-th stop of the left pointer swaps iff the iA-th stop of the right pointer lies right of it
-          if (ge) Bpos[geR] = (uint32_t)j;
-        }
-        if (mloc) atomicAdd(&s_m, mloc);
-      }
-      __syncthreads();
-      const int m = s_m;
-      for (int i = tid; i < m; i += kTieThreads) v.swap((int)Apos[i], (int)Bpos[i]);
-      __syncthreads();
-      if (tid == 0) {
-        // the left pointer's final stop: the next untouched element of A, unless the right pointer's last swap partner comes first
-        const int am = (m < s_totA) ? (int)Apos[m] : 0x7fffffff, bm = (m > 0) ? (int)Bpos[m - 1] : 0x7fffffff;
-        const int cut = am < bm ? am : bm;
-        if (want >= cut) s_first = cut; else s_last = cut;
+      if (!sh.done && tid == 0) {
+        const View v{&lkey[0], &lval[0]};
+        insertion_sort(v, sh.first, sh.last);
+        sh.answer = lval[want - first];
       }
       __syncthreads();
     }
-    if (!s_done) {
-      __syncthreads();
-      if (tid == 0) { insertion_sort(v, s_first, s_last); s_answer = val[want]; }
-      __syncthreads();
-    }
+    TSTAMP(25)
     if (tid == 0) {
-      const uint32_t best = s_answer;
+      const uint32_t best = sh.answer;
       ci->med_pix = (int)best; ci->ambiguous = 2;    // 2 = tie resolved by replaying the reference's sort
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
       o->velocity[0] = (double)a.vx[fN + best]; o->velocity[1] = (double)a.vy[fN + best]; o->velocity[2] = (double)a.vz[fN + best];
