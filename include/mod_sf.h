@@ -187,7 +187,9 @@ int  mod_memcpy_h2d(ModContext *ctx, void *dev_dst, const void *host_src, uint64
 int  mod_memcpy_d2h(ModContext *ctx, void *host_dst, const void *dev_src, uint64_t bytes);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
-/* Stage timers: when enabled, each stage of the next calls is bracketed by HIP events on the context's stream. */
+/* Stage timers: each stage selected by `stage_mask` (bit i = stage i; MOD_PROFILE_ALL for all of them, 0 = off) is
+ * bracketed by HIP events on the context's stream in the calls that follow.  Every event pair costs a few microseconds of
+ * stream time, so a throughput measurement should select only the stage it prices. */
 #define MOD_STAGE_SCENE_FLOW  0   /* k_scene_flow_v4 / _v1: fused scene-flow kernel (+ dynamic mask)            */
 #define MOD_STAGE_CCL_TILE    1   /* k_ccl_tile: tile-local connected components (+ k_dynamic_mask if needed)   */
 #define MOD_STAGE_CCL_LINK    2   /* k_ccl_link: cross-tile unions                                              */
@@ -196,7 +198,8 @@ int  mod_memcpy_d2h(ModContext *ctx, void *host_dst, const void *dev_src, uint64
 #define MOD_STAGE_FINAL       5   /* k_final: labels plane + member compaction                                  */
 #define MOD_STAGE_MEDIAN      6   /* k_median + k_finalize: median-velocity member, object ids                  */
 #define MOD_STAGE_COUNT       7
-int  mod_set_profiling(ModContext *ctx, int32_t enable);
+#define MOD_PROFILE_ALL        0x7f
+int  mod_set_profiling(ModContext *ctx, int32_t stage_mask);
 /* Accumulated milliseconds and launch count of a stage since the last reset (synchronises the stream). */
 int  mod_get_stage_time(ModContext *ctx, int32_t stage, double *total_ms, int64_t *calls);
 int  mod_reset_stage_times(ModContext *ctx);

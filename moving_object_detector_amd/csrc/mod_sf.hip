@@ -55,7 +55,7 @@ struct ModContext {
   FrameConst *pinned[kRing] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t pinned_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
   int ring_pos = 0;
-  bool profiling = false;
+  int profiling = 0;                          // stage mask of mod_set_profiling
   std::vector<EventPair> pending[MOD_STAGE_COUNT];
   std::vector<EventPair> free_events;
   double stage_ms[MOD_STAGE_COUNT] = {};
@@ -132,7 +132,7 @@ int check_ready(ModContext *c, int frames) {
 
 struct StageTimer {
   ModContext *c; int stage; EventPair ev{}; bool on;
-  StageTimer(ModContext *ctx, int st) : c(ctx), stage(st), on(ctx->profiling) {
+  StageTimer(ModContext *ctx, int st) : c(ctx), stage(st), on((ctx->profiling >> st) & 1) {
     if (!on) return;
     if (!c->free_events.empty()) { ev = c->free_events.back(); c->free_events.pop_back(); }
     else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
@@ -565,9 +565,9 @@ int mod_debug_counters(ModContext *c, unsigned long long *out32) {
 }
 
 // ---- measurement -------------------------------------------------------------------------------------------------------
-int mod_set_profiling(ModContext *c, int32_t enable) {
-  if (!c) return MOD_ERR_INVALID_ARGUMENT;
-  c->profiling = enable != 0;
+int mod_set_profiling(ModContext *c, int32_t stage_mask) {
+  if (!c || (stage_mask & ~MOD_PROFILE_ALL)) return MOD_ERR_INVALID_ARGUMENT;
+  c->profiling = stage_mask;
   return MOD_OK;
 }
 int mod_get_stage_time(ModContext *c, int32_t stage, double *total_ms, int64_t *calls) {

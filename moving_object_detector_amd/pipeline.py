@@ -143,8 +143,12 @@ class Context:
         self._check(self.lib.mod_synchronize(self.h))
 
     # ---- measurement ------------------------------------------------------------------------------------------
-    def set_profiling(self, on: bool) -> None:
-        self._check(self.lib.mod_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, on, stages=None) -> None:
+        """Stage timers on/off; `stages` (iterable of MOD_STAGE_*) restricts them to those stages."""
+        mask = 0
+        if on:
+            mask = capi.MOD_PROFILE_ALL if stages is None else sum(1 << int(s) for s in set(stages))
+        self._check(self.lib.mod_set_profiling(self.h, mask))
 
     def reset_stage_times(self) -> None:
         self._check(self.lib.mod_reset_stage_times(self.h))
