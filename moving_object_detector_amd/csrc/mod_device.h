@@ -17,8 +17,8 @@ struct DevCam {
   int32_t debug;           // MOD_DEBUG experiment bits (0 in production): timing ablations only, results become wrong
   float fT;                // F32(f * T)                       disparity_image_processor.cpp:44
   float dmin, dmax;        // min/max_disparity                disparity_image_processor.cpp:25-27
-  float flow_th;           // (float)dynamic_flow_diff         scene_flow_constructor.cpp:198
-  float speed_th;          // smallest F32 t with (double)t >= dynamic_speed   (clusterer_nodelet.cpp:51)
+  float flow_th_sq;        // smallest F32 a with sqrtf(a) >= (float)dynamic_flow_diff   scene_flow_constructor.cpp:198
+  float speed_th_sq;       // smallest F32 a with (double)sqrtf(a) >= dynamic_speed      clusterer_nodelet.cpp:51
   float depth_th;          // largest  F32 t with (double)t <= depth_diff      (clusterer_nodelet.cpp:194)
   double speed_th_d;       // dynamic_speed itself (object acceptance test, clusterer_nodelet.cpp:176)
   double fx, fy, cx, cy, Tx, Ty;  // project3dToPixel, scene_flow_constructor.cpp:84
@@ -67,9 +67,9 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // Plain operators + sqrtf on purpose: the build uses -ffp-contract=off and -fhip-fp32-correctly-rounded-divide-sqrt, whereas
 // HIP's __fsqrt_rn() lowers to the *native* (approximate) square root unless OCML_BASIC_ROUNDED_OPERATIONS is defined.
 #pragma clang fp contract(off)
-__device__ __forceinline__ float norm3_f32(float vx, float vy, float vz) {
+__device__ __forceinline__ float sumsq3_f32(float vx, float vy, float vz) {
   const float xx = vx * vx, yy = vy * vy, zz = vz * vz;
   const float s = yy + zz;
-  const float t = xx + s;
-  return sqrtf(t);
+  return xx + s;
 }
+__device__ __forceinline__ float norm3_f32(float vx, float vy, float vz) { return sqrtf(sumsq3_f32(vx, vy, vz)); }

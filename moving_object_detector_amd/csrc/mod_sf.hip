@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -105,6 +106,20 @@ void transform_to_rows(const ModTransform &tf, double m[12]) {
   m[8] = txz - twy;         m[9] = tyz + twx;         m[10] = 1.0 - (txx + tyy); m[11] = tf.t[2];
 }
 
+// Smallest F32 a >= 0 with sqrtf(a) >= th, so that the kernels test a sum of squares instead of taking its root:
+// sqrtf is correctly rounded (host libm and the device build alike) and therefore monotone, which makes the two tests
+// agree on every input (a NaN fails both; th <= 0 accepts every sum of squares, which is >= +0).
+float sqrt_threshold_sq(float th) {
+  if (std::isnan(th)) return th;                            // never true, like the original comparison
+  if (!(th > 0.0f)) return 0.0f;
+  const float inf = std::numeric_limits<float>::infinity();
+  if (std::isinf(th)) return inf;
+  float a = (float)((double)th * (double)th);
+  while (a > 0.0f && sqrtf(std::nextafterf(a, 0.0f)) >= th) a = std::nextafterf(a, 0.0f);
+  while (a < inf && !(sqrtf(a) >= th)) a = std::nextafterf(a, inf);
+  return a;
+}
+
 void refresh_devcam(ModContext *c) {
   DevCam &d = c->dc;
   d.W = c->cam.width; d.H = c->cam.height;
@@ -114,8 +129,8 @@ void refresh_devcam(ModContext *c) {
   { const char *e = getenv("MOD_DEBUG"); d.debug = e ? atoi(e) : 0; }
   d.fT = c->cam.disp_f * c->cam.disp_T;               // F32 product, exactly the reference's `focal_length * baseline`
   d.dmin = c->cam.min_disparity; d.dmax = c->cam.max_disparity;
-  d.flow_th = (float)c->prm.dynamic_flow_diff;
-  d.speed_th = ceil_to_f32(c->prm.dynamic_speed);
+  d.flow_th_sq = sqrt_threshold_sq((float)c->prm.dynamic_flow_diff);
+  d.speed_th_sq = sqrt_threshold_sq(ceil_to_f32(c->prm.dynamic_speed));
   d.depth_th = floor_to_f32(c->prm.depth_diff);
   d.speed_th_d = c->prm.dynamic_speed;
   d.fx = c->cam.fx; d.fy = c->cam.fy; d.cx = c->cam.cx; d.cy = c->cam.cy; d.Tx = c->cam.Tx; d.Ty = c->cam.Ty;

@@ -42,59 +42,63 @@ __device__ __forceinline__ void iso_apply(const FrameConst &fc, float X, float Y
 // can issue the data-dependent gathers of all its pixels together (one extra memory round trip per thread, not per pixel).
 //   stage 1: static flow at the own pixel, now point, warp target        (needs dn, dpo, flow, own rays)
 //   stage 2: previous point at the warp target, residual test, velocity   (needs disp_prev / rays AT the warp target)
+// The kernel is VALU-bound, not HBM-bound, so the stages are written without control flow: every expression is evaluated
+// for every lane (IEEE special values flow through the arithmetic without traps) and the reference's early-outs become
+// predicates that select between the computed value and NaN.  Tests that a later NaN test subsumes are noted where dropped.
 struct PxState {
   float Xn, Yn, zn, f0, f1;
-  int px, py;          // warp target, clamped into the image when `go` is false
+  int px, py;          // warp target, (0,0) when `go` is false
   bool go;             // every test before the gather passed
 };
+
+__device__ __forceinline__ bool is_nan_or_inf(float v) { return __builtin_isfpclass(v, 0x0207); }   // snan|qnan|-inf|+inf
+// getRightPoint's rejects (scene_flow_constructor.h:211-227): NaN, +-inf or negative (a -0 passes, as `d < 0` is false)
+__device__ __forceinline__ bool is_nan_inf_or_negative(float v) { return __builtin_isfpclass(v, 0x0207 | 0x0018); }
 
 __device__ __forceinline__ void sf_stage1(const DevCam &c, const FrameConst &fc, int x, int y, float dn, float dpo, float f0,
                                           float f1, double rx, double ry, Px &o, PxState &st) {
   const float nan = __uint_as_float(0x7fc00000u);
-  o.x = o.y = o.z = o.vx = o.vy = o.vz = nan;
-  o.s0 = o.s1 = nan;
-  o.depth = nan;
-  o.dyn = false;
-  st.go = false; st.px = 0; st.py = 0; st.f0 = f0; st.f1 = f1;
+  st.f0 = f0; st.f1 = f1;
 
   // ---- static flow at the own pixel: reproject prev, transform, project (always needed by the residual test) ----
   {
-    const bool ok = disp_in_range(c, dpo) && !(dpo == 0.0f);
     const float z = c.fT / dpo;                             // F32
-    const float X = (float)(rx * (double)z);                // F64 product -> F32
-    const float Y = (float)(ry * (double)z);
-    if (ok && !isnan(X)) {
-      float tx, ty, tz;
-      iso_apply(fc, X, Y, z, tx, ty, tz);
-      if (!isnan(tx)) {
-        const double u = (c.fx * (double)tx + c.Tx) / (double)tz + c.cx;     // project3dToPixel, F64
-        const double v = (c.fy * (double)ty + c.Ty) / (double)tz + c.cy;
-        o.s0 = (float)(u - (double)x);
-        o.s1 = (float)(v - (double)y);
-      }
-    }
+    const double zd = (double)z;
+    const float X = (float)(rx * zd);                       // F64 product -> F32
+    const float Y = (float)(ry * zd);
+    float tx, ty, tz;
+    iso_apply(fc, X, Y, z, tx, ty, tz);
+    const double u = (c.fx * (double)tx + c.Tx) / (double)tz + c.cx;     // project3dToPixel, F64
+    const double v = (c.fy * (double)ty + c.Ty) / (double)tz + c.cy;
+    // the reference skips NaN points before and after the transform; a NaN X makes tx NaN, so one test covers both
+    const bool ok = disp_in_range(c, dpo) & !(dpo == 0.0f) & !isnan(tx);
+    o.s0 = ok ? (float)(u - (double)x) : nan;
+    o.s1 = ok ? (float)(v - (double)y) : nan;
   }
 
   // ---- now point ----
-  const bool okn = disp_in_range(c, dn) && !(dn == 0.0f);
+  const bool okn = disp_in_range(c, dn) & !(dn == 0.0f);
   const float zn = c.fT / dn;
-  const float Xn = (float)(rx * (double)zn);
-  const float Yn = (float)(ry * (double)zn);
+  const double znd = (double)zn;
+  const float Xn = (float)(rx * znd);
+  const float Yn = (float)(ry * znd);
   st.Xn = Xn; st.Yn = Yn; st.zn = zn;
-  if (okn) o.depth = zn;                                    // toDepthImage (disparity_image_processor.cpp:105-120)
-  if (!(okn && !isnan(Xn) && !isinf(Xn))) return;           // isValid tests x only (scene_flow_constructor.h:240-249)
-  o.x = Xn; o.y = Yn; o.z = zn;
+  o.depth = okn ? zn : nan;                                 // toDepthImage (disparity_image_processor.cpp:105-120)
+  const bool valid = okn & !is_nan_or_inf(Xn);              // isValid tests x only (scene_flow_constructor.h:240-249)
+  o.x = valid ? Xn : nan; o.y = valid ? Yn : nan; o.z = valid ? zn : nan;
+  o.vx = o.vy = o.vz = nan;
+  o.dyn = false;
 
   // ---- getMatchPoints (scene_flow_constructor.h:173-227) ----
-  if (isnan(f0) || isnan(f1)) return;
   const float rxf = roundf((float)x - f0);                  // std::round, F32, half away from zero
   const float ryf = roundf((float)y - f1);
-  if (isnan(dn) || isinf(dn) || dn < 0.0f) return;          // getRightPoint(now)
-  // out-of-int-range warps are UB in the reference (x86 yields INT_MIN -> rejected by the bounds test): reject.
-  if (!(rxf >= 0.0f && rxf < (float)c.W && ryf >= 0.0f && ryf < (float)c.H)) return;
-  if (isnan(o.s0)) return;                                  // static flow NaN (scene_flow_constructor.cpp:193)
-  st.px = (int)rxf; st.py = (int)ryf;
-  st.go = true;
+  // a NaN flow gives a NaN target, which fails the bounds test below; out-of-int-range warps are UB in the reference
+  // (x86 yields INT_MIN -> rejected by its bounds test): reject.
+  const bool inimg = (rxf >= 0.0f) & (rxf < (float)c.W) & (ryf >= 0.0f) & (ryf < (float)c.H);
+  const bool go = valid & inimg & !is_nan_inf_or_negative(dn)            // getRightPoint(now)
+                & !isnan(o.s0);                                           // static flow NaN (scene_flow_constructor.cpp:193)
+  st.px = go ? (int)rxf : 0; st.py = go ? (int)ryf : 0;
+  st.go = go;
 }
 
 //   dpw = disparity_prev at the warp target, rpx / rpy = F64 rays of its column / row
@@ -107,45 +111,38 @@ struct PxWarp { float Xp, Yp, zp; bool todo, moving; };
 
 __device__ __forceinline__ void sf_stage2a(const DevCam &c, const FrameConst &fc, const PxState &st, float dpw, double rpx,
                                            double rpy, Px &o, PxWarp &wp) {
-  wp.todo = false; wp.moving = false; wp.Xp = wp.Yp = wp.zp = 0.0f;
-  if (!st.go) return;
-  if (!disp_in_range(c, dpw)) return;                       // getRightPoint(previous): getDisparity ...
-  if (isnan(dpw) || isinf(dpw) || dpw < 0.0f) return;       // ... then NaN / inf / negative
-  if (dpw == 0.0f) return;                                  // prev cloud holds NaN there -> !isValid
   const float zp = c.fT / dpw;
-  const float Xp = (float)(rpx * (double)zp);
-  const float Yp = (float)(rpy * (double)zp);
-  if (isnan(Xp)) return;                                    // NaN passes through the transform untouched -> invalid
-  // ---- residual test (scene_flow_constructor.cpp:196-198) ----
+  const double zpd = (double)zp;
+  const float Xp = (float)(rpx * zpd);
+  const float Yp = (float)(rpy * zpd);
+  // getRightPoint(previous): getDisparity range gate, then NaN / inf / negative; a 0 disparity leaves NaN in the previous
+  // cloud (!isValid); a NaN x passes through the transform untouched -> invalid
+  const bool ok = st.go & disp_in_range(c, dpw) & !is_nan_inf_or_negative(dpw) & !(dpw == 0.0f) & !isnan(Xp);
+  // ---- residual test (scene_flow_constructor.cpp:196-198): sqrtf(acc) >= flow_th  <=>  acc >= flow_th_sq (host-derived) ----
   const float r0 = st.f0 - o.s0, r1 = st.f1 - o.s1;
   float acc = 0.0f;
   acc = acc + r0 * r0;
   acc = acc + r1 * r1;
-  const bool moving = sqrtf(acc) >= c.flow_th;
+  const bool moving = acc >= c.flow_th_sq;
   const float safe = (float)fc.pad[0];
-  if (!moving && fabsf(Xp) <= safe && fabsf(Yp) <= safe && fabsf(zp) <= safe) {
-    o.vx = 0.0f; o.vy = 0.0f; o.vz = 0.0f;                  // the transformed point is certainly finite: valid, static
-    o.dyn = 0.0f >= c.speed_th;
-    return;
-  }
-  wp.Xp = Xp; wp.Yp = Yp; wp.zp = zp; wp.todo = true; wp.moving = moving;
+  const bool settled = ok & !moving & (fabsf(Xp) <= safe) & (fabsf(Yp) <= safe) & (fabsf(zp) <= safe);
+  // settled: the transformed point is certainly finite -> valid and static
+  o.vx = settled ? 0.0f : o.vx; o.vy = settled ? 0.0f : o.vy; o.vz = settled ? 0.0f : o.vz;
+  o.dyn = settled & (0.0f >= c.speed_th_sq);
+  wp.Xp = Xp; wp.Yp = Yp; wp.zp = zp; wp.todo = ok & !settled; wp.moving = moving;
 }
 
 __device__ __forceinline__ void sf_stage2b(const DevCam &c, const FrameConst &fc, const PxState &st, const PxWarp &wp, Px &o) {
-  if (!wp.todo) return;
   float tx, ty, tz;
   iso_apply(fc, wp.Xp, wp.Yp, wp.zp, tx, ty, tz);
-  if (isnan(tx) || isinf(tx)) return;
-  if (wp.moving) {                                          // velocity (scene_flow_constructor.cpp:200-202)
-    o.vx = (float)((double)(st.Xn - tx) / fc.dt);
-    o.vy = (float)((double)(st.Yn - ty) / fc.dt);
-    o.vz = (float)((double)(st.zn - tz) / fc.dt);
-    // calculateDynamicMap: (double)||v|| >= dynamic_speed, folded into an equivalent F32 threshold on the host
-    o.dyn = norm3_f32(o.vx, o.vy, o.vz) >= c.speed_th;
-  } else {
-    o.vx = 0.0f; o.vy = 0.0f; o.vz = 0.0f;
-    o.dyn = 0.0f >= c.speed_th;
-  }
+  const bool ok = wp.todo & !is_nan_or_inf(tx);
+  // velocity (scene_flow_constructor.cpp:200-202); 0 when the residual test said "static"
+  const float vx = wp.moving ? (float)((double)(st.Xn - tx) / fc.dt) : 0.0f;
+  const float vy = wp.moving ? (float)((double)(st.Yn - ty) / fc.dt) : 0.0f;
+  const float vz = wp.moving ? (float)((double)(st.zn - tz) / fc.dt) : 0.0f;
+  o.vx = ok ? vx : o.vx; o.vy = ok ? vy : o.vy; o.vz = ok ? vz : o.vz;
+  // calculateDynamicMap: (double)||v|| >= dynamic_speed, folded on the host into an F32 threshold on x^2 + (y^2 + z^2)
+  o.dyn = ok ? (sumsq3_f32(vx, vy, vz) >= c.speed_th_sq) : o.dyn;
 }
 
 __device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, const float *__restrict__ dprev, int x, int y,
@@ -273,7 +270,7 @@ __global__ __launch_bounds__(256) void k_dynamic_mask(DevCam c, const float *__r
   bool dyn = false;
   if (x < c.W && y < c.H) {
     const size_t i = ((size_t)f * c.H + y) * c.W + x;
-    dyn = norm3_f32(vx[i], vy[i], vz[i]) >= c.speed_th;
+    dyn = sumsq3_f32(vx[i], vy[i], vz[i]) >= c.speed_th_sq;
   }
   const uint64_t w = __ballot(dyn);
   if (lane == 0 && y < c.H && blockIdx.x < (unsigned)c.mask_words) mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x] = w;
