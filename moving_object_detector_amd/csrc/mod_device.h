@@ -30,7 +30,8 @@ struct DevCam {
 struct FrameConst {
   double m[12];
   double dt;
-  double pad[3];           // pad[0]: |coordinate| bound below which the transformed point is certainly finite (0 = never)
+  double pad[3];           // [0]: |coordinate| bound below which the transformed point is certainly finite (0 = never)
+                           // [1]: RN(1/dt), [2]: 1 when [1] may replace the division by dt (exact_div.h), else 0
 };
 
 // Per-component record (32 bytes).  Filled by the stats kernel with wave-aggregated atomics.

@@ -1,6 +1,7 @@
 // mod_sf.hip — C ABI (include/mod_sf.h) over the gfx950 kernels: context, scratch, parameter folding, stage timers.
 // Host-side only; the kernels live in sceneflow.hip and cluster.hip.
 #include "../../include/mod_sf.h"
+#include "exact_div.h"
 #include "mod_launch.h"
 
 #include <algorithm>
@@ -192,7 +193,11 @@ int upload_frame_consts(ModContext *c, const ModFrameBatch *in) {
       }
       double B = 0.0;
       if (finite && tmax < 1e37) B = std::min((1.7e38 - tmax) / (3.0 * std::max(mmax, 1e-30)), 1e30);
-      h[f].pad[0] = B; h[f].pad[1] = h[f].pad[2] = 0.0;
+      h[f].pad[0] = B;
+      // velocity = difference / dt through the correctly rounded reciprocal (exact_div.h) when dt is an ordinary number
+      const bool usable = exact_div::reciprocal_usable(h[f].dt);
+      h[f].pad[1] = usable ? 1.0 / h[f].dt : 0.0;
+      h[f].pad[2] = usable ? 1.0 : 0.0;
     }
   }
   HIP_TRY(c, hipMemcpyAsync(c->b.fc, h, sizeof(FrameConst) * in->frames, hipMemcpyHostToDevice, c->stream));

@@ -14,6 +14,7 @@
 // of disp_prev (served by L2 — the warp target is a few rows away) and two F64 ray-table entries.
 // Arithmetic follows the reference expression by expression (F32 vs F64 as annotated); FP contraction is off so
 // that every product and sum rounds exactly like the SSE2 build of the reference.
+#include "exact_div.h"
 #include "mod_launch.h"
 
 #pragma clang fp contract(off)
@@ -51,6 +52,7 @@ struct PxState {
   bool go;             // every test before the gather passed
 };
 
+__device__ __forceinline__ bool is_ordinary(float v) { return __builtin_isfpclass(v, 0x0198); }      // +-normal, +-subnormal
 __device__ __forceinline__ bool is_nan_or_inf(float v) { return __builtin_isfpclass(v, 0x0207); }   // snan|qnan|-inf|+inf
 // getRightPoint's rejects (scene_flow_constructor.h:211-227): NaN, +-inf or negative (a -0 passes, as `d < 0` is false)
 __device__ __forceinline__ bool is_nan_inf_or_negative(float v) { return __builtin_isfpclass(v, 0x0207 | 0x0018); }
@@ -68,10 +70,17 @@ __device__ __forceinline__ void sf_stage1(const DevCam &c, const FrameConst &fc,
     const float Y = (float)(ry * zd);
     float tx, ty, tz;
     iso_apply(fc, X, Y, z, tx, ty, tz);
-    const double u = (c.fx * (double)tx + c.Tx) / (double)tz + c.cx;     // project3dToPixel, F64
-    const double v = (c.fy * (double)ty + c.Ty) / (double)tz + c.cy;
+    // project3dToPixel, F64: (fx X + Tx) / Z + cx and (fy Y + Ty) / Z + cy share one refined reciprocal of Z (exact_div.h)
+    const double A = c.fx * (double)tx + c.Tx, B = c.fy * (double)ty + c.Ty, D = (double)tz;
     // the reference skips NaN points before and after the transform; a NaN X makes tx NaN, so one test covers both
     const bool ok = disp_in_range(c, dpo) & !(dpo == 0.0f) & !isnan(tx);
+    double qa, qb;
+    const bool fast = exact_div::div2_shared(A, B, D, qa, qb);
+    if (__any(ok & !fast)) {                                // operands outside the window: IEEE divisions (rare, wave-uniform)
+      qa = fast ? qa : A / D;
+      qb = fast ? qb : B / D;
+    }
+    const double u = qa + c.cx, v = qb + c.cy;
     o.s0 = ok ? (float)(u - (double)x) : nan;
     o.s1 = ok ? (float)(v - (double)y) : nan;
   }
@@ -136,10 +145,18 @@ __device__ __forceinline__ void sf_stage2b(const DevCam &c, const FrameConst &fc
   float tx, ty, tz;
   iso_apply(fc, wp.Xp, wp.Yp, wp.zp, tx, ty, tz);
   const bool ok = wp.todo & !is_nan_or_inf(tx);
-  // velocity (scene_flow_constructor.cpp:200-202); 0 when the residual test said "static"
-  const float vx = wp.moving ? (float)((double)(st.Xn - tx) / fc.dt) : 0.0f;
-  const float vy = wp.moving ? (float)((double)(st.Yn - ty) / fc.dt) : 0.0f;
-  const float vz = wp.moving ? (float)((double)(st.zn - tz) / fc.dt) : 0.0f;
+  // velocity (scene_flow_constructor.cpp:200-202); 0 when the residual test said "static".  The F64 division by the frame's dt
+  // uses the host's correctly rounded 1/dt (FrameConst.pad[1], exact_div.h) unless dt is outside the usable window.
+  const float dx = st.Xn - tx, dy = st.Yn - ty, dz = st.zn - tz;
+  float vx, vy, vz;
+  if (fc.pad[2] != 0.0) {
+    vx = (float)exact_div::div_by_known((double)dx, is_ordinary(dx), fc.dt, fc.pad[1]);
+    vy = (float)exact_div::div_by_known((double)dy, is_ordinary(dy), fc.dt, fc.pad[1]);
+    vz = (float)exact_div::div_by_known((double)dz, is_ordinary(dz), fc.dt, fc.pad[1]);
+  } else {
+    vx = (float)((double)dx / fc.dt); vy = (float)((double)dy / fc.dt); vz = (float)((double)dz / fc.dt);
+  }
+  vx = wp.moving ? vx : 0.0f; vy = wp.moving ? vy : 0.0f; vz = wp.moving ? vz : 0.0f;
   o.vx = ok ? vx : o.vx; o.vy = ok ? vy : o.vy; o.vz = ok ? vz : o.vz;
   // calculateDynamicMap: (double)||v|| >= dynamic_speed, folded on the host into an F32 threshold on x^2 + (y^2 + z^2)
   o.dyn = ok ? (sumsq3_f32(vx, vy, vz) >= c.speed_th_sq) : o.dyn;
@@ -164,71 +181,102 @@ __device__ __forceinline__ uint64_t nibbles_to_word(uint32_t nib, int lane) {
   return (uint64_t)v | ((uint64_t)hi << 32);
 }
 
+// Addressing: a wave-uniform 64-bit base (frame plane, in SGPRs) plus a 32-bit byte offset per lane, which is the
+// `global_load/store v, v_off, s[base]` form — no 64-bit address arithmetic on the vector unit (the kernel is VALU-bound).
+// mod_set_camera guarantees W*H*32 < 2^32.
+template <class T> __device__ __forceinline__ T ld(const void *base, uint32_t byte_off) {
+  return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+template <class T> __device__ __forceinline__ void st(void *base, uint32_t byte_off, const T &v) {
+  *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
 // Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
 __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const int lane = threadIdx.x;                      // 0..63
-  const int x0 = (blockIdx.x * 64 + lane) * 4;
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  const int f = blockIdx.z;
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), and each XCD has
+  // its own L2.  Remapping the linear id so that XCD k walks the k-th contiguous eighth of the batch keeps the rows a
+  // block's flow-warp gathers touch in the L2 that fetched them for the neighbouring blocks.
+  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7u) == 0u && !(c.debug & 64)) {
+      const uint32_t lin = bx + gridDim.x * (by + gridDim.y * bz);
+      const uint32_t m = (lin & 7u) * (total >> 3) + (lin >> 3);
+      bx = m % gridDim.x;
+      const uint32_t t = m / gridDim.x;
+      by = t % gridDim.y; bz = t / gridDim.y;
+    }
+  }
+  const int x0 = (bx * 64 + lane) * 4;
+  const int y = by * 4 + threadIdx.y;
+  const int f = bz;
   const bool inb = (x0 < c.W) && (y < c.H);
-  const size_t N = (size_t)c.W * c.H;
-  const size_t base = (size_t)f * N + (size_t)y * c.W + x0;
+  const size_t fN = (size_t)f * ((size_t)c.W * c.H);         // wave-uniform
+  const uint32_t pix = (uint32_t)y * (uint32_t)c.W + (uint32_t)x0;
+  const uint32_t o4 = pix * 4u, o8 = pix * 8u;
   const FrameConst fc = a.fc[f];
   uint32_t nib = 0;
   if (inb) {
-    const float4 dn = *reinterpret_cast<const float4 *>(a.dnow + base);
-    const float4 dp = *reinterpret_cast<const float4 *>(a.dprev + base);
-    const float4 fa = *reinterpret_cast<const float4 *>(a.flow + 2 * base);
-    const float4 fb = *reinterpret_cast<const float4 *>(a.flow + 2 * base + 4);
+    const float *dprev_f = a.dprev + fN;
+    const float4 dn = ld<float4>(a.dnow + fN, o4);
+    const float4 dp = ld<float4>(dprev_f, o4);
+    const float4 fa = ld<float4>(a.flow + 2 * fN, o8);
+    const float4 fb = ld<float4>(a.flow + 2 * fN, o8 + 16u);
     const double ry = c.rayy[y];
-    const double2 rxa = *reinterpret_cast<const double2 *>(c.rayx + x0);
-    const double2 rxb = *reinterpret_cast<const double2 *>(c.rayx + x0 + 2);
-    const float *dprev_f = a.dprev + (size_t)f * N;
+    const double2 rxa = ld<double2>(c.rayx, (uint32_t)x0 * 8u);
+    const double2 rxb = ld<double2>(c.rayx, (uint32_t)x0 * 8u + 16u);
     Px p0, p1, p2, p3;
     PxState s0, s1, s2, s3;
     sf_stage1(c, fc, x0 + 0, y, dn.x, dp.x, fa.x, fa.y, rxa.x, ry, p0, s0);
     sf_stage1(c, fc, x0 + 1, y, dn.y, dp.y, fa.z, fa.w, rxa.y, ry, p1, s1);
     sf_stage1(c, fc, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2, s2);
     sf_stage1(c, fc, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3, s3);
-    // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image (clamped) targets
-    const float g0 = dprev_f[(size_t)s0.py * c.W + s0.px], g1 = dprev_f[(size_t)s1.py * c.W + s1.px];
-    const float g2 = dprev_f[(size_t)s2.py * c.W + s2.px], g3 = dprev_f[(size_t)s3.py * c.W + s3.px];
-    const double ax0 = c.rayx[s0.px], ax1 = c.rayx[s1.px], ax2 = c.rayx[s2.px], ax3 = c.rayx[s3.px];
-    const double ay0 = c.rayy[s0.py], ay1 = c.rayy[s1.py], ay2 = c.rayy[s2.py], ay3 = c.rayy[s3.py];
+    // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets
+    const uint32_t W = (uint32_t)c.W;
+    const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
+    const float g1 = ld<float>(dprev_f, ((uint32_t)s1.py * W + (uint32_t)s1.px) * 4u);
+    const float g2 = ld<float>(dprev_f, ((uint32_t)s2.py * W + (uint32_t)s2.px) * 4u);
+    const float g3 = ld<float>(dprev_f, ((uint32_t)s3.py * W + (uint32_t)s3.px) * 4u);
+    const double ax0 = ld<double>(c.rayx, (uint32_t)s0.px * 8u), ax1 = ld<double>(c.rayx, (uint32_t)s1.px * 8u);
+    const double ax2 = ld<double>(c.rayx, (uint32_t)s2.px * 8u), ax3 = ld<double>(c.rayx, (uint32_t)s3.px * 8u);
+    const double ay0 = ld<double>(c.rayy, (uint32_t)s0.py * 8u), ay1 = ld<double>(c.rayy, (uint32_t)s1.py * 8u);
+    const double ay2 = ld<double>(c.rayy, (uint32_t)s2.py * 8u), ay3 = ld<double>(c.rayy, (uint32_t)s3.py * 8u);
     PxWarp w0, w1, w2, w3;
     sf_stage2a(c, fc, s0, g0, ax0, ay0, p0, w0);
     sf_stage2a(c, fc, s1, g1, ax1, ay1, p1, w1);
     sf_stage2a(c, fc, s2, g2, ax2, ay2, p2, w2);
     sf_stage2a(c, fc, s3, g3, ax3, ay3, p3, w3);
-    if (__any(w0.todo || w1.todo || w2.todo || w3.todo)) {   // wave-uniform: some pixel moves (or has extreme coordinates)
+    if (__any(w0.todo | w1.todo | w2.todo | w3.todo)) {      // wave-uniform: some pixel moves (or has extreme coordinates)
       sf_stage2b(c, fc, s0, w0, p0);
       sf_stage2b(c, fc, s1, w1, p1);
       sf_stage2b(c, fc, s2, w2, p2);
       sf_stage2b(c, fc, s3, w3, p3);
     }
-    *reinterpret_cast<float4 *>(a.x + base) = make_float4(p0.x, p1.x, p2.x, p3.x);
-    *reinterpret_cast<float4 *>(a.y + base) = make_float4(p0.y, p1.y, p2.y, p3.y);
-    *reinterpret_cast<float4 *>(a.z + base) = make_float4(p0.z, p1.z, p2.z, p3.z);
-    *reinterpret_cast<float4 *>(a.vx + base) = make_float4(p0.vx, p1.vx, p2.vx, p3.vx);
-    *reinterpret_cast<float4 *>(a.vy + base) = make_float4(p0.vy, p1.vy, p2.vy, p3.vy);
-    *reinterpret_cast<float4 *>(a.vz + base) = make_float4(p0.vz, p1.vz, p2.vz, p3.vz);
+    st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
+    st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
+    st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
+    st(a.vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
+    st(a.vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
+    st(a.vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
     if (a.aos) {   // pcl::PointXYZVelocity records, 32 B each (pads written as 0)
-      float4 *q = a.aos + 2 * base;
-      q[0] = make_float4(p0.x, p0.y, p0.z, 0.f); q[1] = make_float4(p0.vx, p0.vy, p0.vz, 0.f);
-      q[2] = make_float4(p1.x, p1.y, p1.z, 0.f); q[3] = make_float4(p1.vx, p1.vy, p1.vz, 0.f);
-      q[4] = make_float4(p2.x, p2.y, p2.z, 0.f); q[5] = make_float4(p2.vx, p2.vy, p2.vz, 0.f);
-      q[6] = make_float4(p3.x, p3.y, p3.z, 0.f); q[7] = make_float4(p3.vx, p3.vy, p3.vz, 0.f);
+      float4 *q = a.aos + 2 * fN;
+      const uint32_t o32 = pix * 32u;
+      st(q, o32, make_float4(p0.x, p0.y, p0.z, 0.f)); st(q, o32 + 16u, make_float4(p0.vx, p0.vy, p0.vz, 0.f));
+      st(q, o32 + 32u, make_float4(p1.x, p1.y, p1.z, 0.f)); st(q, o32 + 48u, make_float4(p1.vx, p1.vy, p1.vz, 0.f));
+      st(q, o32 + 64u, make_float4(p2.x, p2.y, p2.z, 0.f)); st(q, o32 + 80u, make_float4(p2.vx, p2.vy, p2.vz, 0.f));
+      st(q, o32 + 96u, make_float4(p3.x, p3.y, p3.z, 0.f)); st(q, o32 + 112u, make_float4(p3.vx, p3.vy, p3.vz, 0.f));
     }
-    if (a.depth) *reinterpret_cast<float4 *>(a.depth + base) = make_float4(p0.depth, p1.depth, p2.depth, p3.depth);
+    if (a.depth) st(a.depth + fN, o4, make_float4(p0.depth, p1.depth, p2.depth, p3.depth));
     if (a.sflow) {
-      *reinterpret_cast<float4 *>(a.sflow + 2 * base) = make_float4(p0.s0, p0.s1, p1.s0, p1.s1);
-      *reinterpret_cast<float4 *>(a.sflow + 2 * base + 4) = make_float4(p2.s0, p2.s1, p3.s0, p3.s1);
+      st(a.sflow + 2 * fN, o8, make_float4(p0.s0, p0.s1, p1.s0, p1.s1));
+      st(a.sflow + 2 * fN, o8 + 16u, make_float4(p2.s0, p2.s1, p3.s0, p3.s1));
     }
     nib = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u) | (p2.dyn ? 4u : 0u) | (p3.dyn ? 8u : 0u);
   }
   if (a.mask) {   // wave-uniform branch; all 64 lanes take part in the shuffles
     const uint64_t w = nibbles_to_word(nib, lane);
-    const int word = (blockIdx.x * 64 + lane) / 16;          // (x0 / 64)
+    const int word = (bx * 64 + lane) / 16;                  // (x0 / 64)
     if ((lane & 15) == 0 && y < c.H && word < c.mask_words)
       a.mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
   }

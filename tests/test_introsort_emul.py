@@ -12,3 +12,13 @@ def test_introsort_emulation_matches_libstdcxx(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok")
+
+
+def test_exact_div_known_reciprocal_matches_ieee_division(tmp_path):
+    """csrc/exact_div.h div_by_known (velocity / dt through the host's 1/dt) against `/` on 40 M operand pairs."""
+    exe = str(tmp_path / "exact_div_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "cpp", "exact_div_test.cpp"),
+                           "-o", exe])
+    r = subprocess.run([exe, "100000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("OK")
