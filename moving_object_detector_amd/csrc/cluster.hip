@@ -167,7 +167,7 @@ __device__ __forceinline__ void wave_unite_lds(int *L, bool need, int &cur, int 
 //      only), tile roots get an empty statistics record
 //   D  partial statistics (size, first_edge_key, bbox) of the tile's components, one set of atomics per (wave, root)
 template <int TH, int NMAX>
-__global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ccl_tile(DevCam c, ClArgs a) {
   constexpr int RPW = TH / 4;                       // rows per wave
   constexpr int PW = 64 + NMAX, PH = TH + NMAX, G = PW * PH;
   __shared__ float zt[G];
@@ -333,22 +333,30 @@ __global__ __launch_bounds__(256) void k_ccl_tile(DevCam c, ClArgs a) {
       if (__ballot(nb != 0) == 0) continue;          // wave-uniform
       COUNT(9, 1)
       const int base = qg * PW + NMAX + lane;
-      // pass 1, branch-free: all LDS reads first, then one bit per window position (k = columns to the left)
-      float zq[NMAX + 1];
+      // pass 1, branch-free: labels first, one bit per window position (k = columns to the left)
       int lq[NMAX + 1];
 #pragma unroll
-      for (int k = 0; k <= NMAX; k++) { zq[k] = zt[base - k]; lq[k] = ld_relaxed(&Lt[base - k]); }
-      uint32_t gmask = 0, dmask = 0;                 // bit k: depth gate passes / label differs from this pixel's
+      for (int k = 0; k <= NMAX; k++) lq[k] = ld_relaxed(&Lt[base - k]);
+      uint32_t dmask = 0;                            // bit k: label differs from this pixel's
 #pragma unroll
-      for (int k = 0; k <= NMAX; k++) {
-        gmask |= (fabsf(zp - zq[k]) > th) ? 0u : (1u << k);   // depthDiff gate (:194); NaN links
-        dmask |= (lq[k] != cur) ? (1u << k) : 0u;
-      }
+      for (int k = 0; k <= NMAX; k++) dmask |= (lq[k] != cur) ? (1u << k) : 0u;
       // nb holds pixel (lane - n + i) at bit i: reverse it so that bit k = pixel (lane - k)
-      uint32_t vmask = (__brev(nb) >> (31 - n)) & gmask;
+      uint32_t cand = __brev(nb) >> (31 - n);
       // (0,0) is p itself; (0,-1) inside the wave is the run link of phase A1, (-1,0) the vertical link of phase A2
-      if (dv == 0) vmask &= (lane > 0) ? ~3u : ~1u;
-      if (dv == 1) vmask &= ~1u;
+      if (dv == 0) cand &= (lane > 0) ? ~3u : ~1u;
+      if (dv == 1) cand &= ~1u;
+      // Inside a blob that phases A1-A3 already merged, every candidate carries this pixel's label and the pixel has its
+      // up-left edge: the depth gate cannot change anything, so its LDS reads and compares are skipped (wave-uniform).
+      if (__ballot(((cand & dmask) != 0) | (!up & (cand != 0))) == 0) continue;
+      COUNT(14, 1)
+      COUNT(15, __popcll(__ballot((cand & dmask) != 0)) ? 1 : 0)
+      float zq[NMAX + 1];
+#pragma unroll
+      for (int k = 0; k <= NMAX; k++) zq[k] = zt[base - k];
+      uint32_t gmask = 0;                            // bit k: depth gate passes
+#pragma unroll
+      for (int k = 0; k <= NMAX; k++) gmask |= (fabsf(zp - zq[k]) > th) ? 0u : (1u << k);   // depthDiff gate (:194); NaN links
+      const uint32_t vmask = cand & gmask;
       // halo cells (the whole row when it lies above the tile, else the columns left of it) are nodes of their own
       const uint32_t hmask = (qg < NMAX) ? ~0u : ((lane < 31) ? ~((2u << lane) - 1u) : 0u);
       bool need_any = (vmask & dmask & ~hmask) != 0;

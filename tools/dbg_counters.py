@@ -25,4 +25,4 @@ tot = sum(out[i] for i in range(9))
 for i, n in enumerate(names):
     print(f"{n:16s} {out[i]:14d} cycles  {100.0*out[i]/max(tot,1):5.1f}%   max per wave {out[16+i]:10d}")
 
-print("rows in B", out[13], " (row,dv) iterations", out[9], " pass-2 triggers", out[10], " lanes needing", out[11], " wave_unite calls", out[12])
+print("rows in B", out[13], " (row,dv) iterations", out[9], " pass-2 triggers", out[10], " lanes needing", out[11], " wave_unite calls", out[12], " iterations past the label skip", out[14], " of which with a differing label", out[15])
