@@ -506,58 +506,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   if (tid == 0) { hdr[0] = 1; hdr[1] = s_nreq; }   // s_nreq is final: the barrier after the request loop has passed
 }
 
-// Cross-tile links.  One workgroup per tile walks the tile's requests (halo pixel h, tile root r): h's own tile has
-// published parent[h] = its tile root by now, so the union is between two tile roots — all parent writes here are
-// atomicMin hooks on root entries.  Consecutive requests usually name the same pair; only the first lane of a run acts.
-template <int TH>
-__global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a) {
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x, f = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
-  const size_t tidx = (size_t)f * gridDim.y * gridDim.x + tile;
-  const int *hdr = a.tilehdr + tidx * 2;
-  const int nreq = hdr[1];
-  if (hdr[0] == 0 || nreq == 0) return;
+// Cross-tile links.  One WAVE per tile (most tiles have no dynamic pixel and no request: a workgroup each would spend the
+// kernel on workgroup dispatch), kLinkTilesPerWave tiles per wave so that their headers are fetched together.  The wave
+// walks a tile's requests (halo pixel h, tile root r): h's own tile has published parent[h] = its tile root by now, so the
+// union is between two tile roots — all parent writes here are atomicMin hooks on root entries.  Consecutive requests
+// usually name the same pair; only the first lane of a run acts.
+constexpr int kLinkTilesPerWave = 1, kMergeTilesPerWave = 4;
+
+__global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_per_frame) {
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 4 + wv) * kLinkTilesPerWave;
+  int h0 = 0, h1 = 0;
+  if (lane < kLinkTilesPerWave && t0 + lane < tiles_per_frame) {
+    const int *hdr = a.tilehdr + ((size_t)f * tiles_per_frame + t0 + lane) * 2;
+    h0 = hdr[0]; h1 = hdr[1];
+  }
   const size_t N = (size_t)c.W * c.H;
   int *parent = a.parent + (size_t)f * N;
-  const uint2 *req = a.requests + tidx * a.req_cap;
-  for (int i0 = 0; i0 < nreq; i0 += 256) {
-    const int i = i0 + tid;
-    int ra = -1, rb = -1;
-    if (i < nreq) { const uint2 q = req[i]; ra = parent[q.x]; rb = (int)q.y; }
-    const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
-    if (ra >= 0 && !(lane > 0 && pa == ra && pb == rb)) uf_unite(parent, ra, rb);
+  for (int u = 0; u < kLinkTilesPerWave; u++) {
+    const int nreq = __shfl(h0, u) ? __shfl(h1, u) : 0;
+    if (nreq == 0) continue;                           // wave-uniform
+    const uint2 *req = a.requests + ((size_t)f * tiles_per_frame + t0 + u) * a.req_cap;
+    for (int i0 = 0; i0 < nreq; i0 += 64) {
+      const int i = i0 + lane;
+      int ra = -1, rb = -1;
+      if (i < nreq) { const uint2 q = req[i]; ra = parent[q.x]; rb = (int)q.y; }
+      const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
+      if (ra >= 0 && !(lane > 0 && pa == ra && pb == rb)) uf_unite(parent, ra, rb);
+    }
   }
 }
 
-// Root-level flatten.  One workgroup per tile: every tile root finds its final root, remembers it (path compression,
-// so pixels are two hops from their final root), and folds its partial record into the final root's record; final
-// roots list themselves for k_select.
+// Root-level flatten, one wave per tile like k_ccl_link: every tile root finds its final root, remembers it (path
+// compression, so pixels are two hops from their final root), and folds its partial record into the final root's record;
+// final roots list themselves for k_select.
 template <int TH>
-__global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a) {
-  const int wi = blockIdx.x, f = blockIdx.z, lane = threadIdx.x, w = threadIdx.y;
-  const size_t tidx = (size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi;
-  if (a.tilehdr[tidx * 2] == 0) return;
+__global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles_per_frame) {
+  static_assert(TH <= 64, "one lane per tile row");
+  const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int t0 = (blockIdx.x * 4 + wv) * kMergeTilesPerWave;
+  int h0 = 0;
+  if (lane < kMergeTilesPerWave && t0 + lane < tiles_per_frame) h0 = a.tilehdr[((size_t)f * tiles_per_frame + t0 + lane) * 2];
   const size_t N = (size_t)c.W * c.H;
   int *parent = a.parent + (size_t)f * N;
   CompRec *recs = a.comps + (size_t)f * N;
-  for (int j = w; j < TH; j += 4) {
-    const int y = blockIdx.y * TH + j;
-    if (y >= c.H) break;
-    const uint64_t rb = a.lroot[((size_t)f * c.H + y) * c.mask_words + wi];
-    if (!((rb >> lane) & 1ull)) continue;
-    const int p = y * c.W + wi * 64 + lane;
-    const int r = uf_find(parent, p);
-    if (r == p) {
-      const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
-      a.rootlist[(size_t)f * N + slot] = p;
-    } else {
-      parent[p] = r;   // r is final: no union runs after k_ccl_link
-      const CompRec mine = recs[p];
-      CompRec *t = recs + r;
-      atomicAdd(&t->size, mine.size);
-      if (mine.key != kKeyNone) atomicMin(&t->key, mine.key);
-      atomicMin(&t->mn[0], mine.mn[0]); atomicMax(&t->mx[0], mine.mx[0]);
-      atomicMin(&t->mn[1], mine.mn[1]); atomicMax(&t->mx[1], mine.mx[1]);
-      atomicMin(&t->mn[2], mine.mn[2]); atomicMax(&t->mx[2], mine.mx[2]);
+  for (int u = 0; u < kMergeTilesPerWave; u++) {
+    if (!__shfl(h0, u)) continue;                      // wave-uniform: nothing dynamic in the tile
+    const int t = t0 + u, wi = t % c.mask_words, ty = t / c.mask_words;
+    // lane j holds the root bits of the tile's row j
+    const int yrow = ty * TH + lane;
+    unsigned long long mine = 0ull;
+    if (lane < TH && yrow < c.H) mine = a.lroot[((size_t)f * c.H + yrow) * c.mask_words + wi];
+    unsigned long long rows = __ballot(mine != 0ull);
+    while (rows) {                                     // wave-uniform
+      const int j = __ffsll(rows) - 1;
+      rows &= rows - 1ull;
+      const unsigned long long rb = __shfl(mine, j);
+      if (!((rb >> lane) & 1ull)) continue;
+      const int p = (ty * TH + j) * c.W + wi * 64 + lane;
+      const int r = uf_find(parent, p);
+      if (r == p) {
+        const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
+        a.rootlist[(size_t)f * N + slot] = p;
+      } else {
+        parent[p] = r;   // r is final: no union runs after k_ccl_link
+        const CompRec rec = recs[p];
+        CompRec *t2 = recs + r;
+        atomicAdd(&t2->size, rec.size);
+        if (rec.key != kKeyNone) atomicMin(&t2->key, rec.key);
+        atomicMin(&t2->mn[0], rec.mn[0]); atomicMax(&t2->mx[0], rec.mx[0]);
+        atomicMin(&t2->mn[1], rec.mn[1]); atomicMax(&t2->mx[1], rec.mx[1]);
+        atomicMin(&t2->mn[2], rec.mn[2]); atomicMax(&t2->mx[2], rec.mx[2]);
+      }
     }
   }
 }
@@ -1241,10 +1261,14 @@ void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
   else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16>), tgrid, block, 0, s, c, a);
 }
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  hipLaunchKernelGGL(k_ccl_link<kTileH>, tile_grid(c, frames), dim3(256), 0, s, c, a);
+  const dim3 g = tile_grid(c, frames);
+  const int tiles = (int)(g.x * g.y), per_block = 4 * kLinkTilesPerWave;
+  hipLaunchKernelGGL(k_ccl_link, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles);
 }
 void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  hipLaunchKernelGGL(k_ccl_merge<kTileH>, tile_grid(c, frames), dim3(64, 4, 1), 0, s, c, a);
+  const dim3 g = tile_grid(c, frames);
+  const int tiles = (int)(g.x * g.y), per_block = 4 * kMergeTilesPerWave;
+  hipLaunchKernelGGL(k_ccl_merge<kTileH>, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles);
 }
 void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // the second ClusterInfo array (rank scratch) lives right behind the first one
