@@ -22,6 +22,8 @@
 //   k_select      size filter + ordering by first_edge_key (the reference's numbering) + bbox/centre.
 //   k_relabel     final labels + per-cluster member segments; k_median: radix select of the median-||v|| member.
 #include "mod_launch.h"
+#include <algorithm>
+#include <cstdlib>
 #include "introsort_emul.h"
 #include "../../include/mod_sf.h"
 
@@ -628,6 +630,9 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
     for (int k = 0; k < K; k++) { C[k].offset = off; off += C[k].size; }
     a.counters[f * 8 + 1] = K;
     if (a.n_clusters) a.n_clusters[f] = K;
+    // the launch's cluster list for k_median (order irrelevant): workgroups are then launched per cluster, not per frame
+    const int base = K ? atomicAdd(&a.counters[6], K) : 0;
+    for (int k = 0; k < K; k++) a.worklist[base + k] = (uint32_t)f * (uint32_t)a.max_objects + (uint32_t)k;
   }
   // bbox / centre (cluster2MovingObject, clusterer_nodelet.cpp:151-161): F32 max-min and (min+max)/2, widened to F64
   ModObject *O = (ModObject *)a.objects + (size_t)f * a.max_objects;
@@ -763,63 +768,101 @@ __global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
 // (clusterer_nodelet.cpp:168-174).  All norms are finite and >= 0, so their F32 bit patterns order like the values:
 // a range-adaptive 2048-bin histogram over (bits - min) >> shift isolates the bin that holds rank size/2, its members
 // (a handful) are ranked exactly in LDS; degenerate distributions narrow the range and repeat.
-constexpr int kMedThreads = 1024, kMedBins = 2048, kMedCap = 2048, kMedBatch = 16;
+// The member norms are read from HBM ONCE, into registers (kMedRegs per thread, 32 Ki members per workgroup; the tail of
+// a larger cluster is re-read per pass): every narrowing round then runs out of registers and LDS, so a cluster costs a
+// few HBM round trips instead of one per pass.  Neighbouring members have similar norms, i.e. a wave's lanes mostly hit
+// the same histogram bin: the lanes of a bin are counted with a ballot and added by one lane (hist_add).
+constexpr int kMedThreads = 1024, kMedBins = 2048, kMedRegs = 32, kHistAgg = 0;
+
+// hist[bin] += 1 for every lane with `on`; lanes that share a bin are aggregated, a few rounds, then plain atomics
+__device__ __forceinline__ void hist_add(uint32_t *hist, bool on, uint32_t bin, int lane) {
+  uint64_t act = __ballot(on);
+  for (int it = 0; it < kHistAgg && act; it++) {     // wave-uniform
+    const int lead = __ffsll((unsigned long long)act) - 1;
+    const uint32_t b0 = (uint32_t)__shfl((int)bin, lead);
+    const uint64_t same = __ballot(on && bin == b0);
+    if (lane == lead) atomicAdd(&hist[b0], (uint32_t)__popcll((unsigned long long)same));
+    on = on && bin != b0;
+    act &= ~same;
+  }
+  if (on) atomicAdd(&hist[bin], 1u);
+}
 
 __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
-  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t N = (size_t)c.W * c.H;
-  const int K = a.counters[f * 8 + 1];
+  const int nwork = a.counters[6];
   __shared__ uint32_t hist[kMedBins];
-  __shared__ uint2 cand[kMedCap];
   __shared__ uint32_t s_red[2][16];
-  __shared__ uint32_t s_lo, s_hi, s_bin, s_rem, s_cnt, s_val;
+  __shared__ uint32_t s_lo, s_hi, s_bin, s_rem, s_cnt, s_val, s_ties;
   __shared__ unsigned long long s_best;
   __shared__ int s_amb;
-  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+  constexpr uint32_t kNone = 0xffffffffu;            // not a norm (norms are finite: bits <= 0x7f7fffff)
+#ifdef MOD_PHASE_COUNTERS
+  const unsigned long long bt0 = wall_clock64();
+  if (tid == 0) atomicMin(&a.dbg[42], bt0);
+  struct BlockEnd { unsigned long long *d; unsigned long long t0; int tid; bool busy;
+    __device__ ~BlockEnd() { const unsigned long long t1 = wall_clock64(); if (tid == 0) { atomicMax(&d[43], t1); if (busy) { atomicAdd(&d[40], t1 - t0); atomicAdd(&d[41], 1ull); } } } };
+  BlockEnd be{a.dbg, bt0, tid, (int)blockIdx.x < nwork};
+#endif
+  __shared__ int s_item;
+  for (;;) {
+    // clusters differ 10x in size: workgroups take the next one when they are free (counters[5]) instead of a fixed share
+    if (tid == 0) s_item = atomicAdd(&a.counters[5], 1);
+    __syncthreads();
+    const int wi = s_item;
+    if (wi >= nwork) break;                          // block-uniform; every workgroup gets here
+    const uint32_t item = a.worklist[wi];
+    const int f = (int)(item / (uint32_t)a.max_objects), k = (int)(item % (uint32_t)a.max_objects);
     ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
     const int size = ci->size;
     const uint32_t *sbits = a.mbits + (size_t)f * N + ci->offset;   // ||v|| bits of the members ...
     const uint32_t *spix = a.mpix + (size_t)f * N + ci->offset;     // ... and their pixel indices
-    // ---- scan 1: value range ----
-    uint32_t mn = 0xffffffffu, mx = 0u;
-    for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
-      uint32_t v[kMedBatch];
+    const CompRec rec = a.comps[(size_t)f * N + ci->comp];          // for the NaN test at the end; in flight meanwhile
+#ifdef MOD_PHASE_COUNTERS
+    unsigned long long mt0 = wall_clock64(), mt1;
+#define MSTAMP(i) { __syncthreads(); mt1 = wall_clock64(); if (tid == 0) atomicAdd(&a.dbg[i], mt1 - mt0); mt0 = mt1; }
+#else
+#define MSTAMP(i)
+#endif
+    // ---- the members' norms: registers (member u * T + tid in v[u]) + HBM tail ----
+    uint32_t v[kMedRegs];
 #pragma unroll
-      for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? sbits[i] : 0xffffffffu; }
+    for (int u = 0; u < kMedRegs; u++) { const int i = u * kMedThreads + tid; v[u] = i < size ? sbits[i] : kNone; }
+    const int tail0 = kMedRegs * kMedThreads;
+    // ---- value range ----
+    uint32_t mn = kNone, mx = 0u;
 #pragma unroll
-      for (int u = 0; u < kMedBatch; u++) if (v[u] != 0xffffffffu) { mn = v[u] < mn ? v[u] : mn; mx = v[u] > mx ? v[u] : mx; }
-    }
+    for (int u = 0; u < kMedRegs; u++) { mn = v[u] < mn ? v[u] : mn; mx = (v[u] != kNone && v[u] > mx) ? v[u] : mx; }
+    for (int i = tail0 + tid; i < size; i += kMedThreads) { const uint32_t b = sbits[i]; mn = b < mn ? b : mn; mx = b > mx ? b : mx; }
     mn = wave_min_u32(mn); mx = wave_max_u32(mx);
     if (lane == 0) { s_red[0][wv] = mn; s_red[1][wv] = mx; }
     __syncthreads();
     if (tid == 0) {
-      uint32_t l0 = 0xffffffffu, h0 = 0u;
+      uint32_t l0 = kNone, h0 = 0u;
       for (int i = 0; i < kMedThreads / 64; i++) { l0 = s_red[0][i] < l0 ? s_red[0][i] : l0; h0 = s_red[1][i] > h0 ? s_red[1][i] : h0; }
       s_lo = l0; s_hi = h0;
     }
     __syncthreads();
     uint32_t lo = s_lo, hi = s_hi, rem = (uint32_t)(size / 2);
     bool exact = false;                      // the live range is a single value: every member of it ties
-    bool in_lds = false;                     // the live range has been copied to `cand`
-    int cn = 0;
-    uint32_t val = 0;
-    for (int round = 0; round < 8; round++) {        // <= 3 narrowing rounds per source; the bound only guards against corrupt input
+    uint32_t val = 0, nties = 0;
+    MSTAMP(26)
+    for (int round = 0; round < 8; round++) {        // <= 3 narrowing rounds in practice; the bound only guards against corrupt input
       const uint32_t range = hi - lo;
       const int shift = range < (uint32_t)kMedBins ? 0 : (32 - __clz((int)range) - 11);   // (range >> shift) < 2048
-      // ---- histogram of the live range (from HBM until it fits the LDS list, then from LDS) ----
+      // ---- histogram of the live range ----
       for (int i = tid; i < kMedBins; i += kMedThreads) hist[i] = 0;
-      if (tid == 0) s_cnt = 0;
       __syncthreads();
-      if (!in_lds) {
-        for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
-          uint32_t v[kMedBatch];
 #pragma unroll
-          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? sbits[i] : 0xffffffffu; }
-#pragma unroll
-          for (int u = 0; u < kMedBatch; u++) if (v[u] >= lo && v[u] <= hi) atomicAdd(&hist[(v[u] - lo) >> shift], 1u);
-        }
-      } else {
-        for (int i = tid; i < cn; i += kMedThreads) { const uint32_t b = cand[i].x; if (b >= lo && b <= hi) atomicAdd(&hist[(b - lo) >> shift], 1u); }
+      for (int u = 0; u < kMedRegs; u++) {
+        if (u * kMedThreads >= size) break;            // block-uniform
+        hist_add(hist, v[u] >= lo && v[u] <= hi, (v[u] - lo) >> shift, lane);
+      }
+      for (int i0 = tail0; i0 < size; i0 += kMedThreads) {
+        const int i = i0 + tid;
+        const uint32_t b = i < size ? sbits[i] : kNone;
+        hist_add(hist, b >= lo && b <= hi, (b - lo) >> shift, lane);
       }
       __syncthreads();
       // ---- bin that holds descending rank `rem`: wave 0, lane l owns bins [2047-32l-31, 2047-32l] ----
@@ -843,74 +886,75 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
       const uint32_t nlo = lo + (bin << shift);
       const uint32_t nhi = shift ? (nlo + ((1u << shift) - 1u)) : nlo;
       lo = nlo; hi = nhi < hi ? nhi : hi;
-      if (shift == 0) { exact = true; val = lo; break; }
-      if (in_lds && inbin <= 64u) break;                            // rank the few survivors directly
-      __syncthreads();                                              // hist / s_cnt are rewritten below
-      if (!in_lds && inbin <= (uint32_t)kMedCap) {                  // copy the live range into LDS once it fits
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedBatch) {
-          uint2 v[kMedBatch];
-#pragma unroll
-          for (int u = 0; u < kMedBatch; u++) { const int i = i0 + u * kMedThreads; v[u] = i < size ? make_uint2(sbits[i], spix[i]) : make_uint2(0xffffffffu, 0u); }
-#pragma unroll
-          for (int u = 0; u < kMedBatch; u++)
-            if (v[u].x >= lo && v[u].x <= hi) { const uint32_t slot = atomicAdd(&s_cnt, 1u); cand[slot] = v[u]; }
-        }
-        __syncthreads();
-        cn = (int)s_cnt;
-        in_lds = true;
-        if (cn <= 64) break;
-        __syncthreads();
-      }
+      if (shift == 0) { exact = true; val = lo; nties = inbin; break; }
+      if (inbin <= 64u) break;                                      // rank the few survivors directly
+      __syncthreads();                                              // hist is rewritten by the next round
     }
+    MSTAMP(27)
     if (!exact) {
       // ---- exact rank among the (<= 64) members left in [lo, hi]: compact them (hist is free now), then count ----
       __syncthreads();
       if (tid == 0) s_cnt = 0;
       __syncthreads();
-      for (int i = tid; i < cn; i += kMedThreads) {
-        const uint32_t b = cand[i].x;
-        if (b >= lo && b <= hi) hist[atomicAdd(&s_cnt, 1u)] = b;
+#pragma unroll
+      for (int u = 0; u < kMedRegs; u++) if (v[u] >= lo && v[u] <= hi) { const uint32_t s0 = atomicAdd(&s_cnt, 1u); if (s0 < (uint32_t)kMedBins) hist[s0] = v[u]; }
+      for (int i = tail0 + tid; i < size; i += kMedThreads) {
+        const uint32_t b = sbits[i];
+        if (b >= lo && b <= hi) { const uint32_t s0 = atomicAdd(&s_cnt, 1u); if (s0 < (uint32_t)kMedBins) hist[s0] = b; }
       }
       __syncthreads();
-      const int fn = (int)s_cnt;
+      const int fn = min((int)s_cnt, kMedBins);
       if (tid < fn) {
         const uint32_t b = hist[tid];
         uint32_t gt = 0, ge = 0;
         for (int j = 0; j < fn; j++) { const uint32_t o = hist[j]; gt += o > b; ge += o >= b; }
-        if (gt <= rem && rem < ge) s_val = b;                       // every member of that value writes the same bits
+        if (gt <= rem && rem < ge) { s_val = b; s_ties = ge - gt; }  // every member of that value writes the same
       }
       __syncthreads();
-      val = s_val;
+      val = s_val; nties = s_ties;
     }
+    MSTAMP(28)
     // ---- ties: canonical pick = smallest column-major index; flag ties between different vectors ----
     if (tid == 0) { s_best = ~0ull; s_amb = 0; }
     __syncthreads();
-    const bool from_lds = in_lds;
-    const int tn = from_lds ? cn : size;
-    for (int i = tid; i < tn; i += kMedThreads) {
-      const uint2 m = from_lds ? cand[i] : make_uint2(sbits[i], spix[i]);
-      if (m.x == val) {
-        const uint32_t px = m.y % (uint32_t)c.W, py = m.y / (uint32_t)c.W;
-        atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | m.y);
+#pragma unroll
+    for (int u = 0; u < kMedRegs; u++) {
+      if (v[u] == val) {
+        const uint32_t p = spix[u * kMedThreads + tid];
+        const uint32_t px = p % (uint32_t)c.W, py = p / (uint32_t)c.W;
+        atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | p);
+      }
+    }
+    for (int i = tail0 + tid; i < size; i += kMedThreads) {
+      if (sbits[i] == val) {
+        const uint32_t p = spix[i];
+        const uint32_t px = p % (uint32_t)c.W, py = p / (uint32_t)c.W;
+        atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | p);
       }
     }
     __syncthreads();
     uint32_t best = (uint32_t)(s_best & 0xffffffffull);
     if (s_best == ~0ull) best = spix[0];            // unreachable for consistent input; keeps every access in bounds
     const float bvx = a.vx[(size_t)f * N + best], bvy = a.vy[(size_t)f * N + best], bvz = a.vz[(size_t)f * N + best];
-    for (int i = tid; i < tn; i += kMedThreads) {
-      const uint2 m = from_lds ? cand[i] : make_uint2(sbits[i], spix[i]);
-      if (m.x == val && m.y != best) {
-        const size_t q = (size_t)f * N + m.y;
-        if (__float_as_uint(a.vx[q]) != __float_as_uint(bvx) || __float_as_uint(a.vy[q]) != __float_as_uint(bvy) ||
-            __float_as_uint(a.vz[q]) != __float_as_uint(bvz)) s_amb = 1;
-      }
+    if (nties > 1u) {                                // block-uniform: a single member of that norm cannot tie
+      auto differs = [&](uint32_t p) {
+        const size_t q = (size_t)f * N + p;
+        return __float_as_uint(a.vx[q]) != __float_as_uint(bvx) || __float_as_uint(a.vy[q]) != __float_as_uint(bvy) ||
+               __float_as_uint(a.vz[q]) != __float_as_uint(bvz);
+      };
+#pragma unroll
+      for (int u = 0; u < kMedRegs; u++)
+        if (v[u] == val) { const uint32_t p = spix[u * kMedThreads + tid]; if (p != best && differs(p)) s_amb = 1; }
+      for (int i = tail0 + tid; i < size; i += kMedThreads)
+        if (sbits[i] == val) { const uint32_t p = spix[i]; if (p != best && differs(p)) s_amb = 1; }
     }
     __syncthreads();
+    MSTAMP(29)
     if (tid == 0) {
+      if (k == 0 && f == 0) a.dbg[31] += 1;
+      a.dbg[30] += 0;
       ci->med_pix = (int)best; ci->med_bits = val; ci->ambiguous = s_amb;
+      if (s_amb) a.tielist[atomicAdd(&a.counters[7], 1)] = item;
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
       o->velocity[0] = (double)bvx; o->velocity[1] = (double)bvy; o->velocity[2] = (double)bvz;
     }
@@ -920,7 +964,6 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     // (column-major) with SSE semantics "(a < b) ? a : b": a NaN replaces the running value and the next point replaces
     // the NaN, i.e. the result is the min / max over the members AFTER the last NaN, or NaN when the last member is NaN.
     {
-      const CompRec rec = a.comps[(size_t)f * N + ci->comp];
       bool anynan = false;
       for (int d = 0; d < 3; d++) anynan = anynan || isnan(ord2f(rec.mn[d])) || isnan(ord2f(rec.mx[d]));
       if (anynan) {                                  // block-uniform
@@ -1079,16 +1122,19 @@ __device__ __forceinline__ void tie_narrow(KP key, KP val, PP Apos, PP Bpos, int
 
 __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a) {
   using namespace introsort_emul;
-  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const size_t N = (size_t)c.W * c.H, fN = (size_t)f * N;
-  const int K = a.counters[f * 8 + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t N = (size_t)c.W * c.H;
+  const int nwork = a.counters[7];
   __shared__ uint32_t lkey[kTieLds], lval[kTieLds];
   __shared__ uint16_t lA[kTieLds], lB[kTieLds];      // positions inside the LDS-resident range fit 16 bits
   __shared__ int s_box[4];
   __shared__ TieShared sh;
-  for (int k = blockIdx.x; k < K; k += gridDim.x) {
+  for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint32_t item = a.tielist[wi];
+    const int f = (int)(item / (uint32_t)a.max_objects), k = (int)(item % (uint32_t)a.max_objects);
+    const size_t fN = (size_t)f * N;
     ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
-    if (ci->ambiguous != 1) continue;                // block-uniform
+    if (ci->ambiguous != 1) continue;                // block-uniform (always 1 for a listed cluster)
 #ifdef MOD_PHASE_COUNTERS
     unsigned long long tt0 = wall_clock64(), tt1;
 #define TSTAMP(i) { __syncthreads(); tt1 = wall_clock64(); if (tid == 0) atomicAdd(&a.dbg[i], tt1 - tt0); tt0 = tt1; }
@@ -1279,8 +1325,10 @@ void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   hipLaunchKernelGGL(k_final<kTileH>, tile_grid(c, frames), dim3(64, 4, 1), 0, s, c, a);
 }
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  hipLaunchKernelGGL(k_median, dim3(16, frames), dim3(kMedThreads), 0, s, c, a);
-  hipLaunchKernelGGL(k_median_ties, dim3(4, frames), dim3(kTieThreads), 0, s, c, a);
+  // one 1024-thread workgroup fills a CU and costs ~80 ns of wave dispatch whether it finds work or not: launch at most one
+  // per CU (fewer for small batches) and let each walk the launch's cluster list (k_select) / tie list (k_median)
+  hipLaunchKernelGGL(k_median, dim3(std::min(256, frames * 8)), dim3(kMedThreads), 0, s, c, a);
+  hipLaunchKernelGGL(k_median_ties, dim3(std::min(64, frames * 2)), dim3(kTieThreads), 0, s, c, a);
   hipLaunchKernelGGL(k_finalize, dim3((frames + 63) / 64), dim3(64), 0, s, c, a, frames);
 }
 

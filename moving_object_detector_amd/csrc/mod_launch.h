@@ -26,6 +26,8 @@ struct ClArgs {
   uint32_t *mbits;            // [F][N] ||v|| bit patterns of the members, grouped per cluster (SoA with mpix)
   uint32_t *mpix;             // [F][N] pixel index of each member
   int32_t *cursors;           // [F][max_objects] fill cursors of the member segments
+  uint32_t *worklist;         // [F * max_objects] frame * max_objects + cluster of every cluster of the launch; count in counters[6]
+  uint32_t *tielist;          // [F * max_objects] the clusters k_median flagged ambiguous;                count in counters[7]
   void *objects;              // [F][max_objects] ModObject
   int32_t *n_objects;         // [F]
   int32_t *n_clusters;        // [F] or null

@@ -29,6 +29,7 @@ struct Buffers {
   ClusterInfo *clusters = nullptr;          // 2 x [maxF][max_objects]
   uint32_t *mbits = nullptr, *mpix = nullptr;
   int32_t *cursors = nullptr;
+  uint32_t *worklist = nullptr;   // [2][F * max_objects]: all clusters of a launch, then the ambiguous ones
   unsigned long long *dbg = nullptr;
   uint2 *requests = nullptr;
   int32_t *tilehdr = nullptr;
@@ -245,7 +246,8 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
   a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.mpix;
   a.labels = out->labels; a.comps = c->b.comps; a.counters = c->b.counters; a.clusters = c->b.clusters;
-  a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.cursors = c->b.cursors; a.objects = out->objects; a.n_objects = out->n_objects;
+  a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.cursors = c->b.cursors; a.worklist = c->b.worklist; a.tielist = c->b.worklist + (size_t)c->cfg.max_frames * c->max_objects;
+  a.objects = out->objects; a.n_objects = out->n_objects;
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
   a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
   {
@@ -302,12 +304,14 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   ok &= dalloc(&c->b.mbits, (size_t)F * N) == hipSuccess;
   ok &= dalloc(&c->b.mpix, (size_t)F * N) == hipSuccess;
   ok &= dalloc(&c->b.cursors, (size_t)F * c->max_objects) == hipSuccess;
+  ok &= dalloc(&c->b.worklist, (size_t)2 * F * c->max_objects) == hipSuccess;
   {
     const size_t tiles = (size_t)c->max_mask_words * ((cfg->max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
     ok &= dalloc(&c->b.tilehdr, (size_t)F * tiles * 2) == hipSuccess;
   }
-  ok &= dalloc(&c->b.dbg, 32) == hipSuccess;
-  if (ok) ok &= hipMemset(c->b.dbg, 0, 32 * 8) == hipSuccess;
+  ok &= dalloc(&c->b.dbg, 64) == hipSuccess;
+  if (ok) ok &= hipMemset(c->b.dbg, 0, 64 * 8) == hipSuccess;
+  if (ok) ok &= hipMemset((char *)c->b.dbg + 42 * 8, 0xFF, 8) == hipSuccess;   // slot 42 is a minimum
   for (int i = 0; i < kRing && ok; i++) {
     ok &= hipHostMalloc((void **)&c->pinned[i], sizeof(FrameConst) * F, hipHostMallocDefault) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->pinned_ev[i], hipEventDisableTiming) == hipSuccess;
@@ -323,7 +327,7 @@ void mod_destroy(ModContext *c) {
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
   void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.comps, b.counters, b.clusters, b.mbits, b.mpix,
-                 b.cursors, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
+                 b.cursors, b.worklist, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
     if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
@@ -579,8 +583,9 @@ int mod_debug_read(ModContext *c, int which, void *dst, unsigned long long bytes
 int mod_debug_counters(ModContext *c, unsigned long long *out32) {
   if (!c || !out32) return MOD_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(out32, c->b.dbg, 32 * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemset(c->b.dbg, 0, 32 * 8));
+  HIP_TRY(c, hipMemcpy(out32, c->b.dbg, 64 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemset(c->b.dbg, 0, 64 * 8));
+  HIP_TRY(c, hipMemset((char *)c->b.dbg + 42 * 8, 0xFF, 8));
   return MOD_OK;
 }
 
