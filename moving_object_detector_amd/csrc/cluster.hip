@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (tid >= NMAX && v0) s_any = 1;
   }
   __syncthreads();
-  const int r0 = w * RPW;
+  // rows are dealt to the waves round-robin (wave w owns rows w, w + 4, ...): a blob's rows are contiguous, so contiguous
+  // row blocks would leave most of a tile's work to one wave while the others wait at the barriers
   int *hdr = a.tilehdr + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * 2;
   if (!s_any) {                                     // nothing dynamic inside the tile
     if (tid == 0) { hdr[0] = 0; hdr[1] = 0; }
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const int xc = min(x0 + lane, c.W - 1), xhc = max(x0 - 1 - lane, 0);
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const size_t gp = fN + (size_t)min(y0 + r0 + j, c.H - 1) * c.W + xc;
+    const size_t gp = fN + (size_t)min(y0 + w + 4 * j, c.H - 1) * c.W + xc;
     xr[j] = a.x[gp];
     yr[j] = a.y[gp];
   }
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   bool upr[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
+    const int rr = w + 4 * j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX];
     const bool dyn = (mw >> lane) & 1ull;
     const float z = zt[me];
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // ---- phase A2: vertical pre-link (the pixel straight above), one union per distinct (run, run-above) pair -----------
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
+    const int rr = w + 4 * j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX], mu = m0[rr + NMAX - 1];
     if ((mw & mu) == 0 || (c.debug & 2048)) continue;                    // wave-uniform
     const bool v = ((mw & mu) >> lane) & 1ull;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // ---- phase A3: flatten, so that phase B can compare labels directly; note rows whose dynamic pixels share one label --
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = r0 + j, me = (rr + NMAX) * PW + NMAX + lane;
+    const int rr = w + 4 * j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX];
     const bool dyn = (mw >> lane) & 1ull;
     int lab = -1;
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const uint32_t kmask = (2u << n) - 1u;              // n + 1 low bits
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = r0 + j;
+    const int rr = w + 4 * j;
     const uint64_t mw = m0[rr + NMAX];
     if (mw == 0 || (c.debug & 256)) continue;                           // wave-uniform
     const bool dyn = (mw >> lane) & 1ull;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   uint64_t rootbits[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = r0 + j, gy = y0 + rr;
+    const int rr = w + 4 * j, gy = y0 + rr;
     const bool dyn = (m0[rr + NMAX] >> lane) & 1ull;
     int rg = -1, rc = -1;
     bool isroot = false;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   STAMP(7)
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = r0 + j, gy = y0 + rr;
+    const int rr = w + 4 * j, gy = y0 + rr;
     if (m0[rr + NMAX] == 0 || (c.debug & 520)) continue;                // wave-uniform
     const int rg = rootg[j];
     uint32_t ox = 0, oy = 0, oz = 0, key = (uint32_t)kKeyNone;
