@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=128, help="stereo pairs per step and per GPU")
+    ap.add_argument("--frames", type=int, default=512, help="stereo pairs per step and per GPU")
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs generated per GPU (tiled to --frames)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
