@@ -168,9 +168,9 @@ __device__ __forceinline__ void wave_unite_lds(int *L, bool need, int &cur, int 
 //   C  publish: interior pixels hook onto their tile root, linked halo pixels are united with it in HBM (atomicMin
 //      only), tile roots get an empty statistics record
 //   D  partial statistics (size, first_edge_key, bbox) of the tile's components, one set of atomics per (wave, root)
-template <int TH, int NMAX>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ccl_tile(DevCam c, ClArgs a) {
-  constexpr int RPW = TH / 4;                       // rows per wave
+template <int TH, int NMAX, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ccl_tile(DevCam c, ClArgs a) {
+  constexpr int RPW = TH / NW;                      // rows per wave (NW waves per tile)
   constexpr int PW = 64 + NMAX, PH = TH + NMAX, G = PW * PH;
   __shared__ float zt[G];
   __shared__ int Lt[G];
@@ -220,25 +220,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // ---- phase A: masked depth + identity parents; grid row gr = image row y0 - NMAX + gr, 4 rows per step -----------
   // All HBM reads of the kernel are issued here, unconditionally (clamped addresses, values of non-dynamic pixels are
   // discarded): predicated loads would compile to one exec-masked branch + wait each, i.e. one round trip per row.
-  constexpr int AROWS = (PH + 3) / 4;
+  constexpr int AROWS = (PH + NW - 1) / NW;
   float xr[RPW], yr[RPW], zl[AROWS], zh[AROWS];
   const int xc = min(x0 + lane, c.W - 1), xhc = max(x0 - 1 - lane, 0);
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const size_t gp = fN + (size_t)min(y0 + w + 4 * j, c.H - 1) * c.W + xc;
+    const size_t gp = fN + (size_t)min(y0 + w + NW * j, c.H - 1) * c.W + xc;
     xr[j] = a.x[gp];
     yr[j] = a.y[gp];
   }
 #pragma unroll
   for (int i = 0; i < AROWS; i++) {
-    const int gy = min(max(y0 - NMAX + w + 4 * i, 0), c.H - 1);
+    const int gy = min(max(y0 - NMAX + w + NW * i, 0), c.H - 1);
     const size_t rowp = fN + (size_t)gy * c.W;
     zl[i] = a.z[rowp + xc];
     zh[i] = a.z[rowp + xhc];                          // left halo: column x0 - 1 - lane (lanes < n)
   }
 #pragma unroll
   for (int i = 0; i < AROWS; i++) {
-    const int gr = w + 4 * i;
+    const int gr = w + NW * i;
     if (gr < PH) {
       const uint64_t q0 = m0[gr], qL = mL[gr];        // zero for rows that are unused or outside the image
       const int cell = gr * PW + NMAX + lane;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   bool upr[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = w + 4 * j, me = (rr + NMAX) * PW + NMAX + lane;
+    const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX];
     const bool dyn = (mw >> lane) & 1ull;
     const float z = zt[me];
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // ---- phase A2: vertical pre-link (the pixel straight above), one union per distinct (run, run-above) pair -----------
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = w + 4 * j, me = (rr + NMAX) * PW + NMAX + lane;
+    const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX], mu = m0[rr + NMAX - 1];
     if ((mw & mu) == 0 || (c.debug & 2048)) continue;                    // wave-uniform
     const bool v = ((mw & mu) >> lane) & 1ull;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   // ---- phase A3: flatten, so that phase B can compare labels directly; note rows whose dynamic pixels share one label --
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = w + 4 * j, me = (rr + NMAX) * PW + NMAX + lane;
+    const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX];
     const bool dyn = (mw >> lane) & 1ull;
     int lab = -1;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   const uint32_t kmask = (2u << n) - 1u;              // n + 1 low bits
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = w + 4 * j;
+    const int rr = w + NW * j;
     const uint64_t mw = m0[rr + NMAX];
     if (mw == 0 || (c.debug & 256)) continue;                           // wave-uniform
     const bool dyn = (mw >> lane) & 1ull;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   uint64_t rootbits[RPW];
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = w + 4 * j, gy = y0 + rr;
+    const int rr = w + NW * j, gy = y0 + rr;
     const bool dyn = (m0[rr + NMAX] >> lane) & 1ull;
     int rg = -1, rc = -1;
     bool isroot = false;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int topcells = n * (64 + n);               // n rows x (n + 64) columns above the tile
     const int total = topcells + TH * n;             // + TH rows x n columns left of it
     uint2 *req = a.requests + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * a.req_cap;
-    for (int i0 = 0; i0 < total && !(c.debug & 1024); i0 += 256) {
+    for (int i0 = 0; i0 < total && !(c.debug & 1024); i0 += NW * 64) {
       const int i = i0 + tid;
       bool linked = false;
       int hg = 0, rg = 0;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   STAMP(7)
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = w + 4 * j, gy = y0 + rr;
+    const int rr = w + NW * j, gy = y0 + rr;
     if (m0[rr + NMAX] == 0 || (c.debug & 520)) continue;                // wave-uniform
     const int rg = rootg[j];
     uint32_t ox = 0, oy = 0, oz = 0, key = (uint32_t)kKeyNone;
@@ -656,9 +656,9 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
 // plane is written here, 4 B/px).  A pixel's parent entry names its tile root, so the few tile roots resolve their final
 // root's new label once (into LDS) and every pixel just looks it up; members of surviving clusters are counted per tile
 // root in LDS, one cursor atomic per (tile root) reserves their slots, then (||v|| bits, pixel) records are appended.
-template <int TH>
-__global__ __launch_bounds__(256) void k_final(DevCam c, ClArgs a) {
-  constexpr int RPW = TH / 4;
+template <int TH, int NW>
+__global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
+  constexpr int RPW = TH / NW;
   __shared__ int nlmap[TH * 64];                     // per tile-root cell: new label of its component (or -1)
   __shared__ int lcount[TH * 64];                    // per tile-root cell: member count, then base slot of its members
   const int wi = blockIdx.x, f = blockIdx.z, lane = threadIdx.x, w = threadIdx.y;
@@ -1295,17 +1295,17 @@ __global__ void k_finalize(DevCam c, ClArgs a, int frames) {
   a.n_objects[f] = n;
 }
 
-constexpr int kTileH = 16;
+constexpr int kTileH = 16, kTileWaves = 4;   // tile = 64 x 16 px, 4 rows per wave (measured best of 8x4, 16x4, 16x8, 32x8)
 
 }  // namespace
 
 static dim3 tile_grid(const DevCam &c, int frames) { return dim3(c.mask_words, (c.H + kTileH - 1) / kTileH, frames); }
 
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  const dim3 block(64, 4, 1), tgrid = tile_grid(c, frames);
-  if (c.n <= 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4>), tgrid, block, 0, s, c, a);
-  else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8>), tgrid, block, 0, s, c, a);
-  else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16>), tgrid, block, 0, s, c, a);
+  const dim3 block(64, kTileWaves, 1), tgrid = tile_grid(c, frames);
+  if (c.n <= 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves>), tgrid, block, 0, s, c, a);
+  else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves>), tgrid, block, 0, s, c, a);
+  else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16, kTileWaves>), tgrid, block, 0, s, c, a);
 }
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 g = tile_grid(c, frames);
@@ -1323,7 +1323,7 @@ void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) 
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
 }
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  hipLaunchKernelGGL(k_final<kTileH>, tile_grid(c, frames), dim3(64, 4, 1), 0, s, c, a);
+  hipLaunchKernelGGL((k_final<kTileH, kTileWaves>), tile_grid(c, frames), dim3(64, kTileWaves, 1), 0, s, c, a);
 }
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // one 1024-thread workgroup fills a CU and costs ~80 ns of wave dispatch whether it finds work or not: launch at most one
