@@ -7,7 +7,7 @@ src = "gpurun_out/final"
 os.makedirs("profiles", exist_ok=True)
 bench = json.load(open(f"{src}/bench_default.json"))
 json.dump(bench, open(f"profiles/{tag}_bench.json", "w"), indent=1)
-stats = glob.glob(f"{src}/stats/*/*_kernel_stats.csv")[0]
+stats = max(glob.glob(f"{src}/stats/*/*_kernel_stats.csv"), key=os.path.getmtime)   # newest run only
 rows = list(csv.DictReader(open(stats)))
 with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
@@ -18,7 +18,7 @@ traffic = {"frames_per_launch": F, "width": 1280, "height": 720, "source": "rocp
 per = collections.defaultdict(dict)
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for fcsv in glob.glob(f"{src}/pmc_{ctr}/*/*counter_collection.csv"):
+    for fcsv in [max(glob.glob(f"{src}/pmc_{ctr}/*/*counter_collection.csv"), key=os.path.getmtime)]:   # newest run only
         for r in csv.DictReader(open(fcsv)):
             m = re.search(r"(k_\w+)", r["Kernel_Name"])
             if not m: continue
