@@ -48,7 +48,7 @@ typedef struct ModConfig {
   int32_t device;       /* HIP device ordinal */
   int32_t max_width;    /* largest image width  the scratch is sized for */
   int32_t max_height;   /* largest image height the scratch is sized for */
-  int32_t max_frames;   /* largest batch (frames per call) */
+  int32_t max_frames;   /* largest batch (frames per call), <= 65535; max_width * max_height < 2^27 */
   int32_t max_objects;  /* per-frame capacity of the ModObject output; 0 -> max_width*max_height/100 (Clusterer.cfg:8 lower bound).
                            mod_set_params rejects a cluster_size with max_width*max_height/cluster_size > max_objects, so no
                            cluster can ever be dropped */

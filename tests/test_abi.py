@@ -51,6 +51,18 @@ def test_no_device_is_an_error_not_a_fallback():
         Context(64, 48)
 
 
+def test_config_limits_are_checked_before_any_device_work():
+    from moving_object_detector_amd import capi
+    lib = capi.load()
+    h = C.c_void_p()
+    for cfg in (capi.ModConfig(0, 64, 48, 70000, 0, 0, None),        # frames ride in grid.y / grid.z
+                capi.ModConfig(0, 16384, 8192, 1, 0, 0, None),       # 2^27 px: 32-bit byte offsets of the AoS cloud
+                capi.ModConfig(0, 64, 48, 65535, 40000, 0, None),    # frame * max_objects + cluster must fit 31 bits
+                capi.ModConfig(0, 0, 48, 1, 0, 0, None)):
+        assert lib.mod_create(C.byref(cfg), C.byref(h)) == capi.MOD_ERR_INVALID_ARGUMENT
+        assert not h.value
+
+
 def test_missing_library_raises(monkeypatch, tmp_path):
     from moving_object_detector_amd import capi
     monkeypatch.setattr(capi, "_lib", None)
