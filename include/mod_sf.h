@@ -180,6 +180,33 @@ int  mod_cluster_cloud_host(ModContext *ctx, const void *cloud, int32_t width, i
                             int32_t point_step, int32_t row_step,
                             int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects);
 
+/* ---- host streaming: frames in flight, copies overlapped with the kernels --------------------------------------- */
+/* The reference overlaps construct() of frame t with the estimators of frame t+1 (construct_thread_,
+ * scene_flow_constructor.cpp:389-392) and keeps disparity_previous_ from the last callback (:397-398).  Here up to
+ * MOD_PIPELINE_DEPTH frames are in flight: the input copy of frame t+1 and the result copy of frame t-1 run on their own
+ * HIP streams beside the kernels of frame t.
+ *   mod_submit_frame_host  enqueues one frame and returns at once with a ticket.  Arguments as mod_process_frame_host,
+ *       except: disparity_prev may be NULL, then the disparity_now of the previous submit (still resident in HBM) is used
+ *       (MOD_SKIP_NO_DISPARITY_PREV if there was none); outputs are written asynchronously — every pointer must stay valid
+ *       and untouched until the ticket is collected.  Skip codes as construct(); MOD_ERR_CAPACITY when MOD_PIPELINE_DEPTH
+ *       frames are already in flight.  The large buffers (inputs, cloud, labels) should come from mod_host_malloc: a copy
+ *       to or from pageable memory makes the call wait for that copy; `objects` may be ordinary memory (filled at collect time).
+ *   mod_collect_frame_host waits for a ticket (tickets complete in submission order; the oldest one must be collected
+ *       first) and reports its object count.
+ * Camera / parameters must not be changed while frames are in flight. */
+#define MOD_PIPELINE_DEPTH 3
+int  mod_submit_frame_host(ModContext *ctx,
+                           const float *disparity_now, const float *disparity_prev, const float *flow,
+                           const ModTransform *transform, double dt,
+                           void *cloud_aos, int32_t *labels, ModObject *objects, int32_t max_objects,
+                           int32_t *ticket);
+int  mod_collect_frame_host(ModContext *ctx, int32_t ticket, int32_t *n_objects);
+/* disparity_now_.reset() of a failed estimateDisparity (scene_flow_constructor.cpp:272-276): the next submit without an
+ * explicit disparity_prev reports MOD_SKIP_NO_DISPARITY_PREV instead of pairing with a stale frame. */
+int  mod_forget_previous(ModContext *ctx);
+int  mod_host_malloc(ModContext *ctx, uint64_t bytes, void **host_ptr);   /* page-locked host memory */
+int  mod_host_free(ModContext *ctx, void *host_ptr);
+
 /* ---- device memory helpers (so a non-HIP host language can own HBM buffers) ------------------------------- */
 int  mod_malloc(ModContext *ctx, uint64_t bytes, void **dev_ptr);
 int  mod_free(ModContext *ctx, void *dev_ptr);

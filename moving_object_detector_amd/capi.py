@@ -28,6 +28,7 @@ MOD_ERR_NO_DEVICE = -5
 MOD_STAGE_SCENE_FLOW, MOD_STAGE_CCL_TILE, MOD_STAGE_CCL_LINK, MOD_STAGE_CCL_MERGE = 0, 1, 2, 3
 MOD_STAGE_SELECT, MOD_STAGE_FINAL, MOD_STAGE_MEDIAN, MOD_STAGE_COUNT = 4, 5, 6, 7
 MOD_PROFILE_ALL = 0x7F
+MOD_PIPELINE_DEPTH = 3
 STAGE_NAMES = ("k_scene_flow", "k_ccl_tile", "k_ccl_link", "k_ccl_merge", "k_select", "k_final", "k_median+k_finalize")
 
 # every symbol include/mod_sf.h declares (tests check that the library exports all of them)
@@ -35,7 +36,8 @@ EXPORTS = [
     "mod_abi_version", "mod_create", "mod_destroy", "mod_last_error", "mod_set_camera", "mod_set_params",
     "mod_get_camera", "mod_get_params", "mod_synchronize", "mod_scene_flow_dev", "mod_dynamic_mask_dev",
     "mod_cluster_dev", "mod_process_dev", "mod_pack_cloud_dev", "mod_unpack_cloud_dev", "mod_process_frame_host",
-    "mod_cluster_cloud_host", "mod_malloc", "mod_free", "mod_memcpy_h2d", "mod_memcpy_d2h", "mod_set_profiling",
+    "mod_cluster_cloud_host", "mod_submit_frame_host", "mod_collect_frame_host", "mod_forget_previous", "mod_host_malloc", "mod_host_free",
+    "mod_malloc", "mod_free", "mod_memcpy_h2d", "mod_memcpy_d2h", "mod_set_profiling",
     "mod_get_stage_time", "mod_reset_stage_times",
 ]
 
@@ -126,6 +128,11 @@ def load(require_torch_first: bool = True):
     L.mod_process_frame_host.argtypes = [vp, vp, vp, vp, C.POINTER(ModTransform), C.c_double, vp, vp, vp, i32,
                                          C.POINTER(i32)]
     L.mod_cluster_cloud_host.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
+    L.mod_submit_frame_host.argtypes = [vp, vp, vp, vp, C.POINTER(ModTransform), C.c_double, vp, vp, vp, i32, C.POINTER(i32)]
+    L.mod_collect_frame_host.argtypes = [vp, i32, C.POINTER(i32)]
+    L.mod_forget_previous.argtypes = [vp]
+    L.mod_host_malloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
+    L.mod_host_free.argtypes = [vp, vp]
     L.mod_malloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]
     L.mod_free.argtypes = [vp, vp]
     L.mod_memcpy_h2d.argtypes = [vp, vp, vp, C.c_uint64]

@@ -55,6 +55,25 @@ struct ModContext {
   int max_objects = 0;
   size_t maxN = 0;
   int max_mask_words = 0;
+  // host streaming (mod_submit_frame_host): per-slot device buffers, a ring of MOD_PIPELINE_DEPTH + 1 disparity planes
+  // (frame t's plane is frame t+1's "previous"), two copy streams and the events that order them with the kernels
+  struct Pipe {
+    bool ready = false;
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    float *dnow[MOD_PIPELINE_DEPTH + 1] = {}, *dprev[MOD_PIPELINE_DEPTH] = {}, *flow[MOD_PIPELINE_DEPTH] = {};
+    float *planes[MOD_PIPELINE_DEPTH] = {};
+    void *aos[MOD_PIPELINE_DEPTH] = {};
+    int32_t *labels[MOD_PIPELINE_DEPTH] = {}, *nobj[MOD_PIPELINE_DEPTH] = {};
+    ModObject *objects[MOD_PIPELINE_DEPTH] = {};
+    int32_t *h_n[MOD_PIPELINE_DEPTH] = {};         // pinned: object count of the slot's frame
+    ModObject *h_obj[MOD_PIPELINE_DEPTH] = {};     // pinned: its objects (handed to the caller's array at collect time)
+    ModObject *user_obj[MOD_PIPELINE_DEPTH] = {};
+    int32_t user_cap[MOD_PIPELINE_DEPTH] = {};
+    hipEvent_t ev_in[MOD_PIPELINE_DEPTH] = {}, ev_done[MOD_PIPELINE_DEPTH] = {}, ev_out[MOD_PIPELINE_DEPTH] = {};
+    int64_t seq = 0;                               // frames submitted so far
+    int in_flight = 0;
+    bool have_prev = false;                        // dnow[(seq - 1) % (DEPTH + 1)] holds the previous frame's disparity
+  } pipe;
   FrameConst *pinned[kRing] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t pinned_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
   int ring_pos = 0;
@@ -340,6 +359,20 @@ void mod_destroy(ModContext *c) {
   }
   for (int s = 0; s < MOD_STAGE_COUNT; s++) for (EventPair &e : c->pending[s]) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (EventPair &e : c->free_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  {
+    ModContext::Pipe &p = c->pipe;
+    if (p.h2d) { (void)hipStreamSynchronize(p.h2d); (void)hipStreamDestroy(p.h2d); }
+    if (p.d2h) { (void)hipStreamSynchronize(p.d2h); (void)hipStreamDestroy(p.d2h); }
+    for (int i = 0; i <= MOD_PIPELINE_DEPTH; i++) if (p.dnow[i]) (void)hipFree(p.dnow[i]);
+    for (int i = 0; i < MOD_PIPELINE_DEPTH; i++) {
+      void *dv[] = {p.dprev[i], p.flow[i], p.planes[i], p.aos[i], p.labels[i], p.nobj[i], p.objects[i]};
+      for (void *q : dv) if (q) (void)hipFree(q);
+      if (p.h_n[i]) (void)hipHostFree(p.h_n[i]);
+      if (p.h_obj[i]) (void)hipHostFree(p.h_obj[i]);
+      hipEvent_t ev[] = {p.ev_in[i], p.ev_done[i], p.ev_out[i]};
+      for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -549,6 +582,120 @@ int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int3
   rc = mod_cluster_dev(c, 1, &pl, &out);
   if (rc) return rc;
   return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
+}
+
+// ---- host streaming ----------------------------------------------------------------------------------------------------
+static int ensure_pipe(ModContext *c) {
+  ModContext::Pipe &p = c->pipe;
+  if (p.ready) return MOD_OK;
+  const size_t N = c->maxN;
+  HIP_TRY(c, hipStreamCreateWithFlags(&p.h2d, hipStreamNonBlocking));
+  HIP_TRY(c, hipStreamCreateWithFlags(&p.d2h, hipStreamNonBlocking));
+  for (int i = 0; i <= MOD_PIPELINE_DEPTH; i++) HIP_TRY(c, dalloc(&p.dnow[i], N));
+  for (int i = 0; i < MOD_PIPELINE_DEPTH; i++) {
+    HIP_TRY(c, dalloc(&p.dprev[i], N));
+    HIP_TRY(c, dalloc(&p.flow[i], 2 * N));
+    HIP_TRY(c, dalloc(&p.planes[i], 6 * N));
+    HIP_TRY(c, hipMalloc(&p.aos[i], 32 * N));
+    HIP_TRY(c, dalloc(&p.labels[i], N));
+    HIP_TRY(c, dalloc(&p.nobj[i], 8));
+    HIP_TRY(c, dalloc(&p.objects[i], (size_t)c->max_objects));
+    HIP_TRY(c, hipHostMalloc((void **)&p.h_n[i], 64, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void **)&p.h_obj[i], sizeof(ModObject) * (size_t)c->max_objects, hipHostMallocDefault));
+    HIP_TRY(c, hipEventCreateWithFlags(&p.ev_in[i], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&p.ev_done[i], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&p.ev_out[i], hipEventDisableTiming));
+  }
+  p.ready = true;
+  return MOD_OK;
+}
+
+int mod_submit_frame_host(ModContext *c, const float *disparity_now, const float *disparity_prev, const float *flow,
+                          const ModTransform *transform, double dt, void *cloud_aos, int32_t *labels, ModObject *objects,
+                          int32_t max_objects, int32_t *ticket) {
+  int rc = check_ready(c, 1);
+  if (rc) return rc;
+  if (!ticket) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null ticket");
+  *ticket = -1;
+  ModContext::Pipe &p = c->pipe;
+  // the guards of construct() (scene_flow_constructor.cpp:104,110,122,127,133), in its order
+  if (!flow) return MOD_SKIP_NO_FLOW;
+  if (!disparity_prev && !p.have_prev) return MOD_SKIP_NO_DISPARITY_PREV;
+  if (!transform) return MOD_SKIP_NO_TRANSFORM;
+  if (!disparity_now) return MOD_SKIP_NO_DISPARITY_NOW;
+  if (p.in_flight >= MOD_PIPELINE_DEPTH) return fail(c, MOD_ERR_CAPACITY, "MOD_PIPELINE_DEPTH frames are already in flight");
+  if ((rc = ensure_pipe(c))) return rc;
+  constexpr int R = MOD_PIPELINE_DEPTH + 1;
+  const int slot = (int)(p.seq % MOD_PIPELINE_DEPTH), nowi = (int)(p.seq % R), previ = (int)((p.seq + R - 1) % R);
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  // inputs: their own stream.  dnow[nowi] was last read by frame seq - R + 1 (as its "previous"), which has been collected:
+  // at most MOD_PIPELINE_DEPTH - 1 frames are in flight at this point.
+  HIP_TRY(c, hipMemcpyAsync(p.dnow[nowi], disparity_now, 4 * N, hipMemcpyHostToDevice, p.h2d));
+  if (disparity_prev) HIP_TRY(c, hipMemcpyAsync(p.dprev[slot], disparity_prev, 4 * N, hipMemcpyHostToDevice, p.h2d));
+  HIP_TRY(c, hipMemcpyAsync(p.flow[slot], flow, 8 * N, hipMemcpyHostToDevice, p.h2d));
+  HIP_TRY(c, hipEventRecord(p.ev_in[slot], p.h2d));
+  // kernels: the context's stream
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, p.ev_in[slot], 0));
+  ModFrameBatch in{};
+  in.frames = 1; in.disparity_now = p.dnow[nowi]; in.disparity_prev = disparity_prev ? p.dprev[slot] : p.dnow[previ];
+  in.flow = p.flow[slot]; in.transforms = transform; in.dt = &dt;
+  ModSceneFlowPlanes pl;
+  memset(&pl, 0, sizeof(pl));
+  float *q = p.planes[slot];
+  pl.x = q; pl.y = q + N; pl.z = q + 2 * N; pl.vx = q + 3 * N; pl.vy = q + 4 * N; pl.vz = q + 5 * N;
+  pl.cloud_aos = cloud_aos ? p.aos[slot] : nullptr;
+  ModClusterOut out{};
+  out.labels = p.labels[slot]; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
+  if ((rc = mod_process_dev(c, &in, &pl, &out))) return rc;
+  HIP_TRY(c, hipEventRecord(p.ev_done[slot], c->stream));
+  // results: their own stream
+  HIP_TRY(c, hipStreamWaitEvent(p.d2h, p.ev_done[slot], 0));
+  HIP_TRY(c, hipMemcpyAsync(p.h_n[slot], p.nobj[slot], sizeof(int32_t), hipMemcpyDeviceToHost, p.d2h));
+  if (labels) HIP_TRY(c, hipMemcpyAsync(labels, p.labels[slot], sizeof(int32_t) * N, hipMemcpyDeviceToHost, p.d2h));
+  // the count is not known yet: the caller's capacity goes to a pinned staging array (a pageable destination would make this
+  // call wait for the kernels); mod_collect_frame_host hands the objects over
+  const int32_t ncopy = objects ? std::max(0, std::min(max_objects, (int32_t)c->max_objects)) : 0;
+  if (ncopy > 0) HIP_TRY(c, hipMemcpyAsync(p.h_obj[slot], p.objects[slot], sizeof(ModObject) * ncopy, hipMemcpyDeviceToHost, p.d2h));
+  p.user_obj[slot] = objects; p.user_cap[slot] = ncopy;
+  if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, p.aos[slot], 32 * N, hipMemcpyDeviceToHost, p.d2h));
+  HIP_TRY(c, hipEventRecord(p.ev_out[slot], p.d2h));
+  *ticket = (int32_t)(p.seq & 0x7fffffff);
+  p.seq++; p.in_flight++; p.have_prev = true;
+  return MOD_OK;
+}
+
+int mod_collect_frame_host(ModContext *c, int32_t ticket, int32_t *n_objects) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  ModContext::Pipe &p = c->pipe;
+  if (n_objects) *n_objects = 0;
+  if (p.in_flight < 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "no frame in flight");
+  const int64_t oldest = p.seq - p.in_flight;
+  if (ticket != (int32_t)(oldest & 0x7fffffff)) return fail(c, MOD_ERR_INVALID_ARGUMENT, "tickets are collected in submission order");
+  const int slot = (int)(oldest % MOD_PIPELINE_DEPTH);
+  HIP_TRY(c, hipEventSynchronize(p.ev_out[slot]));
+  const int32_t n = *p.h_n[slot];
+  if (n_objects) *n_objects = n;
+  const int32_t ncopy = std::min(n, p.user_cap[slot]);
+  if (p.user_obj[slot] && ncopy > 0) memcpy(p.user_obj[slot], p.h_obj[slot], sizeof(ModObject) * (size_t)ncopy);
+  p.in_flight--;
+  return MOD_OK;
+}
+
+int mod_forget_previous(ModContext *c) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  c->pipe.have_prev = false;
+  return MOD_OK;
+}
+
+int mod_host_malloc(ModContext *c, uint64_t bytes, void **p) {
+  if (!c || !p) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipHostMalloc(p, bytes, hipHostMallocDefault));
+  return MOD_OK;
+}
+int mod_host_free(ModContext *c, void *p) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipHostFree(p));
+  return MOD_OK;
 }
 
 // ---- memory helpers --------------------------------------------------------------------------------------------------

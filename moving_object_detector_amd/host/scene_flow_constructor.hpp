@@ -100,9 +100,91 @@ class SceneFlowConstructor {
     return ok;
   }
 
+  // Pipelined stereoCallback(): the reference runs construct() of frame t on construct_thread_ while the estimators of
+  // frame t+1 run (:389-392).  submit() enqueues the frame (copies and kernels proceed on the GPU's streams) and returns a
+  // ticket, or -1 where nothing will be published; collect() joins it and fills the messages handed to submit().  The
+  // previous disparity stays resident in HBM (disparity_previous_ = disparity_now_, :397-398) instead of being copied on
+  // the host.  Up to MOD_PIPELINE_DEPTH frames may be in flight; tickets are collected in order.  The message buffers
+  // (disparity, flow, cloud) should be page-locked (mod_host_malloc) for the copies to overlap.
+  int submit(const mod_host::DisparityImage *disparity_now, const mod_host::FlowImage *left_flow,
+             const mod_host::Transform *transform_prev2now, mod_host::PointCloud2 *pc_with_velocity,
+             mod_host::MovingObjectArray *moving_objects = nullptr) {
+    ModTransform tf{};
+    if (transform_prev2now) {
+      for (int i = 0; i < 3; i++) tf.t[i] = transform_prev2now->translation[i];
+      for (int i = 0; i < 4; i++) tf.q[i] = transform_prev2now->rotation[i];
+    }
+    const double dt = (disparity_now && have_stamp_) ? disparity_now->header.stamp - previous_stamp_ : 0.0;
+    const size_t n = (size_t)image_width_ * image_height_;
+    int32_t ticket = -1;
+    int rc = MOD_SKIP_NO_DISPARITY_NOW;
+    if (disparity_now) {
+      if (pc_with_velocity && pc_with_velocity->data.size() != n * 32) pc_with_velocity->data.resize(n * 32);
+      Pending &p = pending_[next_slot_];
+      p.objects.resize(max_objects_);
+      // previous disparity: resident in HBM from the last enqueued frame, or the host copy parked by a skipped frame
+      rc = mod_submit_frame_host(ctx_, disparity_now->data, have_parked_ ? parked_.data() : nullptr,
+                                 left_flow ? left_flow->data : nullptr, transform_prev2now ? &tf : nullptr, dt,
+                                 pc_with_velocity ? pc_with_velocity->data.data() : nullptr, nullptr, p.objects.data(),
+                                 (int32_t)p.objects.size(), &ticket);
+      if (rc == MOD_OK) {
+        p.ticket = ticket; p.cloud = pc_with_velocity; p.objs = moving_objects; p.header = left_flow->header;
+        next_slot_ = (next_slot_ + 1) % MOD_PIPELINE_DEPTH;
+        have_parked_ = false;
+      } else if (rc > 0) {
+        // nothing was enqueued, so this disparity never reached HBM — yet it IS the next frame's previous one
+        // (disparity_previous_ = disparity_now_ runs whatever construct() did, :398): park a host copy
+        check(mod_forget_previous(ctx_));
+        parked_.assign(disparity_now->data, disparity_now->data + n);
+        have_parked_ = true;
+      }
+      previous_stamp_ = disparity_now->header.stamp; have_stamp_ = true;
+    } else {
+      check(mod_forget_previous(ctx_));   // estimateDisparity failed: disparity_now_.reset() (:272-276)
+      have_stamp_ = false; have_parked_ = false;
+    }
+    if (rc > 0) return -1;
+    check(rc);
+    return ticket;
+  }
+  void collect(int ticket) {
+    for (Pending &p : pending_) {
+      if (p.ticket != ticket) continue;
+      int32_t n_obj = 0;
+      check(mod_collect_frame_host(ctx_, ticket, &n_obj));
+      if (p.cloud) {
+        p.cloud->header = p.header;
+        p.cloud->width = image_width_; p.cloud->height = image_height_;
+        p.cloud->point_step = 32; p.cloud->row_step = 32 * image_width_;
+        p.cloud->is_dense = true;
+      }
+      if (p.objs) {
+        p.objs->header = p.header;
+        p.objs->moving_object_array.clear();
+        for (int i = 0; i < n_obj && i < (int)p.objects.size(); i++) p.objs->moving_object_array.push_back(mod_host::to_message(p.objects[i]));
+      }
+      p.ticket = -1;
+      return;
+    }
+    throw std::runtime_error("collect(): unknown ticket");
+  }
+
   void setMaxObjects(int n) { max_objects_ = n; }
 
  private:
+  struct Pending {
+    int ticket = -1;
+    mod_host::PointCloud2 *cloud = nullptr;
+    mod_host::MovingObjectArray *objs = nullptr;
+    mod_host::Header header;
+    std::vector<ModObject> objects;
+  };
+  Pending pending_[MOD_PIPELINE_DEPTH];
+  int next_slot_ = 0;
+  bool have_stamp_ = false, have_parked_ = false;
+  double previous_stamp_ = 0.0;
+  std::vector<float> parked_;
+
   ModParams currentParams() {
     ModParams p{};
     if (mod_get_params(ctx_, &p) != MOD_OK) {   // reference defaults (SceneFlowConstructor.cfg:8, Clusterer.cfg:8-11)

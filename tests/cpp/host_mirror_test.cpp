@@ -3,6 +3,7 @@
 // which is then fed to the clusterer mirror as a PointCloud2.  Inputs/outputs are raw binary files so that pytest can
 // compare against the golden fixtures (tests/test_gpu_host_mirror.py).  Standalone process: no torch, no Python.
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -82,6 +83,39 @@ int main(int argc, char **argv) {
   clusterer.dataCB(cloud, &objs_cluster, &cluster_map);
   if (objs_cluster.moving_object_array.size() != objs_fused.moving_object_array.size()) { fprintf(stderr, "object count differs\n"); return 6; }
   if (objs_cluster.header.frame_id != "left_camera") { fprintf(stderr, "header not propagated\n"); return 7; }
+
+  // the pipelined form of the same sequence (submit / collect): frame 0 publishes nothing but its disparity becomes frame 1's
+  // previous one; frame 1 gives the same bytes as the synchronous callback; a frame without transform publishes nothing and
+  // the frame after it pairs with it, as in the reference (:397-398)
+  {
+    scene_flow_constructor::SceneFlowConstructor piped(ctx);
+    piped.setCameraInfo(info, now);
+    mod_host::PointCloud2 c1, c2, c3;
+    mod_host::MovingObjectArray o1, o3;
+    const int t0 = piped.submit(&prev, nullptr, nullptr, &c1, &o1);
+    const int t1 = piped.submit(&now, &fl, &tf, &c1, &o1);
+    const int t2 = piped.submit(&now, &fl, nullptr, &c2, nullptr);
+    mod_host::DisparityImage later = now;
+    later.header.stamp = now.header.stamp + tq[7];
+    const int t3 = piped.submit(&later, &fl, &tf, &c3, &o3);        // previous = `now` (parked by the skipped frame)
+    if (t0 != -1 || t1 < 0 || t2 != -1 || t3 < 0) { fprintf(stderr, "ticket pattern wrong: %d %d %d %d\n", t0, t1, t2, t3); return 8; }
+    piped.collect(t1);
+    piped.collect(t3);
+    if (c1.data != cloud.data) { fprintf(stderr, "pipelined cloud differs from the synchronous one\n"); return 9; }
+    if (o1.moving_object_array.size() != objs_fused.moving_object_array.size()) { fprintf(stderr, "pipelined object count differs\n"); return 10; }
+    for (size_t i = 0; i < o1.moving_object_array.size(); i++)
+    {
+      const mod_host::MovingObject &a = o1.moving_object_array[i], &b = objs_fused.moving_object_array[i];   // (the struct has padding)
+      if (a.id != b.id || memcmp(&a.center, &b.center, sizeof(a.center)) || memcmp(a.velocity, b.velocity, sizeof(a.velocity)) ||
+          memcmp(a.bounding_box, b.bounding_box, sizeof(a.bounding_box))) { fprintf(stderr, "pipelined object %zu differs\n", i); return 11; }
+    }
+    // frame 3 paired `now` with itself shifted by dt: must equal the synchronous path fed the same pair
+    mod_host::PointCloud2 c3s;
+    scene_flow_constructor::SceneFlowConstructor again(ctx);
+    again.setCameraInfo(info, now);
+    if (!again.construct(&later, &now, &fl, &tf, &c3s)) { fprintf(stderr, "reference pair not published\n"); return 12; }
+    if (c3.data != c3s.data) { fprintf(stderr, "pipelined frame after a skipped one differs\n"); return 13; }
+  }
 
   write_all(dir + "/cloud.bin", cloud.data.data(), cloud.data.size());
   write_all(dir + "/labels.i32", cluster_map.data(), cluster_map.size() * 4);

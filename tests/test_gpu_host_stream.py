@@ -1,0 +1,114 @@
+"""GPU: mod_submit_frame_host / mod_collect_frame_host (frames in flight, copies on their own streams) against the
+synchronous mod_process_frame_host on the same frames — bit-identical clouds, labels and objects; skip codes and the
+resident previous disparity behave like construct()'s guards and the reference's disparity_previous_."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _sequence(W, H, F, seed):
+    """A real sequence: frame f's previous disparity IS frame f-1's disparity."""
+    from moving_object_detector_amd import synth
+    cam, b = synth.make_batch(W, H, F, seed=seed)
+    for f in range(1, F):
+        b["disparity_prev"][f] = b["disparity_now"][f - 1]
+    return cam, b
+
+
+def test_stream_matches_synchronous_path():
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+    W, H, F, CAP = 320, 240, 7, 32
+    cam, b = _sequence(W, H, F, seed=21)
+    prm = synth.Params(cluster_size=150)
+    N = W * H
+    tfs = capi.transforms_array(b["t"], b["q"])
+
+    def run(stream):
+        ctx = Context(W, H, max_frames=1)
+        ctx.set_camera(cam)
+        ctx.set_params(prm)
+        clouds = np.zeros((F, N, 8), np.float32)
+        labels = np.full((F, N), -7, np.int32)
+        objs = [(capi.ModObject * CAP)() for _ in range(F)]
+        counts = []
+        n = C.c_int32(-1)
+        if not stream:
+            for f in range(F):
+                rc = ctx.lib.mod_process_frame_host(ctx.h, b["disparity_now"][f].ctypes.data, b["disparity_prev"][f].ctypes.data,
+                                                    b["flow"][f].ctypes.data, C.byref(tfs[f]), float(b["dt"][f]), clouds[f].ctypes.data,
+                                                    labels[f].ctypes.data, objs[f], CAP, C.byref(n))
+                assert rc == 0
+                counts.append(n.value)
+        else:
+            tickets = []
+            t = C.c_int32(-1)
+            for f in range(F):
+                if len(tickets) == capi.MOD_PIPELINE_DEPTH:            # full: one more submit is refused, nothing is lost
+                    rc = ctx.lib.mod_submit_frame_host(ctx.h, b["disparity_now"][f].ctypes.data, None, b["flow"][f].ctypes.data,
+                                                       C.byref(tfs[f]), float(b["dt"][f]), None, None, None, 0, C.byref(t))
+                    assert rc == capi.MOD_ERR_CAPACITY and t.value == -1
+                    assert ctx.lib.mod_collect_frame_host(ctx.h, tickets.pop(0), C.byref(n)) == 0
+                    counts.append(n.value)
+                # frame 0 brings its previous disparity; later frames rely on the resident one (odd frames pass it anyway)
+                dp = b["disparity_prev"][f].ctypes.data if (f == 0 or f % 2 == 1) else None
+                rc = ctx.lib.mod_submit_frame_host(ctx.h, b["disparity_now"][f].ctypes.data, dp, b["flow"][f].ctypes.data, C.byref(tfs[f]),
+                                                   float(b["dt"][f]), clouds[f].ctypes.data, labels[f].ctypes.data, objs[f], CAP, C.byref(t))
+                assert rc == 0, ctx.lib.mod_last_error(ctx.h)
+                tickets.append(t.value)
+            # out-of-order collection is refused
+            if len(tickets) > 1:
+                assert ctx.lib.mod_collect_frame_host(ctx.h, tickets[-1], C.byref(n)) == capi.MOD_ERR_INVALID_ARGUMENT
+            while tickets:
+                assert ctx.lib.mod_collect_frame_host(ctx.h, tickets.pop(0), C.byref(n)) == 0
+                counts.append(n.value)
+            assert ctx.lib.mod_collect_frame_host(ctx.h, 0, C.byref(n)) == capi.MOD_ERR_INVALID_ARGUMENT   # nothing in flight
+        ctx.close()
+        return clouds, labels, objs, counts
+
+    c0, l0, o0, n0 = run(False)
+    c1, l1, o1, n1 = run(True)
+    assert n0 == n1 and max(n0) > 0
+    assert np.array_equal(l0, l1)
+    assert np.array_equal(c0.view(np.uint32)[..., [0, 1, 2, 4, 5, 6]], c1.view(np.uint32)[..., [0, 1, 2, 4, 5, 6]])
+    for f in range(F):
+        a = np.frombuffer(bytes(o0[f]), np.uint8)[: 112 * n0[f]]
+        bb = np.frombuffer(bytes(o1[f]), np.uint8)[: 112 * n1[f]]
+        assert np.array_equal(a, bb), f
+
+
+def test_stream_skip_codes_and_resident_previous_disparity():
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+    W, H = 64, 48
+    cam, b = _sequence(W, H, 2, seed=3)
+    ctx = Context(W, H, max_frames=1)
+    ctx.set_camera(cam)
+    ctx.set_params(synth.Params())
+    tfs = capi.transforms_array(b["t"], b["q"])
+    t, n = C.c_int32(5), C.c_int32(0)
+    dn, dp, fl = (b[k][0].ctypes.data for k in ("disparity_now", "disparity_prev", "flow"))
+    sub = lambda a0, a1, a2, tf: ctx.lib.mod_submit_frame_host(ctx.h, a0, a1, a2, tf, 0.1, None, None, None, 0, C.byref(t))
+    assert sub(dn, dp, None, C.byref(tfs[0])) == capi.MOD_SKIP_NO_FLOW and t.value == -1
+    assert sub(dn, None, fl, C.byref(tfs[0])) == capi.MOD_SKIP_NO_DISPARITY_PREV        # first frame: nothing resident yet
+    assert sub(dn, dp, fl, None) == capi.MOD_SKIP_NO_TRANSFORM
+    assert sub(None, dp, fl, C.byref(tfs[0])) == capi.MOD_SKIP_NO_DISPARITY_NOW
+    assert sub(dn, dp, fl, C.byref(tfs[0])) == 0 and t.value == 0
+    assert sub(b["disparity_now"][1].ctypes.data, None, b["flow"][1].ctypes.data, C.byref(tfs[1])) == 0 and t.value == 1
+    assert ctx.lib.mod_collect_frame_host(ctx.h, 0, C.byref(n)) == 0
+    assert ctx.lib.mod_collect_frame_host(ctx.h, 1, C.byref(n)) == 0
+    ctx.close()
+
+
+def test_pinned_host_memory_helpers():
+    from moving_object_detector_amd.pipeline import Context
+    ctx = Context(64, 48, max_frames=1)
+    p = C.c_void_p()
+    assert ctx.lib.mod_host_malloc(ctx.h, 1 << 20, C.byref(p)) == 0 and p.value
+    C.memset(p.value, 0x5A, 1 << 20)
+    assert ctx.lib.mod_host_free(ctx.h, p) == 0
+    ctx.close()
