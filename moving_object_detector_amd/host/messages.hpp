@@ -2,6 +2,7 @@
 // and runs without ROS.  Field names follow the ROS definitions; a ROS build maps the real messages onto these views
 // (ros_adapter/) without copying pixels.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -11,7 +12,32 @@
 
 namespace mod_host {
 
-struct Header { uint32_t seq = 0; double stamp = 0.0; std::string frame_id; };
+// ros::Time: seconds + nanoseconds.  The frame interval of the velocity (scene_flow_constructor.cpp:162-164,200-202) is
+// `(stamp_now - stamp_previous).toSec()`: integer arithmetic on (sec, nsec), normalised to 0 <= nsec < 1e9, then
+// `(double)sec + 1e-9 * (double)nsec` (roscpp_core: rostime/duration.h, impl/duration.h) — NOT the difference of two doubles,
+// which would round differently; velocities are only bit-exact with the reference if dt is formed this way.
+struct Time {
+  uint32_t sec = 0, nsec = 0;
+  Time() = default;
+  Time(uint32_t s, uint32_t ns) : sec(s), nsec(ns) {}
+  static Time fromSec(double t) {                       // ros::TimeBase::fromSec
+    Time r;
+    r.sec = (uint32_t)std::floor(t);
+    r.nsec = (uint32_t)std::floor((t - (double)r.sec) * 1e9 + 0.5);   // boost::math::round for a non-negative value
+    r.sec += r.nsec / 1000000000u; r.nsec %= 1000000000u;
+    return r;
+  }
+  double toSec() const { return (double)sec + 1e-9 * (double)nsec; }
+};
+// (a - b).toSec() of two ros::Time values
+inline double duration_sec(const Time &a, const Time &b) {
+  int64_t sec = (int64_t)a.sec - (int64_t)b.sec, nsec = (int64_t)a.nsec - (int64_t)b.nsec;
+  while (nsec >= 1000000000LL) { nsec -= 1000000000LL; ++sec; }     // normalizeSecNSecSigned
+  while (nsec < 0) { nsec += 1000000000LL; --sec; }
+  return (double)sec + 1e-9 * (double)nsec;
+}
+
+struct Header { uint32_t seq = 0; Time stamp; std::string frame_id; };
 
 // stereo_msgs/DisparityImage: 32FC1 image + f, T, min/max_disparity (disparity_image_processor.cpp:5,25-27,41-42)
 struct DisparityImage {

@@ -18,11 +18,11 @@ void publishSceneFlow(scene_flow_constructor::SceneFlowConstructor &impl, ros::P
   mod_host::FlowImage f;
   mod_host::Transform t;
   if (disparity) {
-    d.header.stamp = disparity->header.stamp.toSec(); d.width = disparity->image.width; d.height = disparity->image.height;
+    d.header.stamp = mod_host::Time(disparity->header.stamp.sec, disparity->header.stamp.nsec); d.width = disparity->image.width; d.height = disparity->image.height;
     d.data = reinterpret_cast<const float *>(disparity->image.data.data());
     d.f = disparity->f; d.T = disparity->T; d.min_disparity = disparity->min_disparity; d.max_disparity = disparity->max_disparity;
   }
-  if (flow) { f.header.stamp = flow->header.stamp.toSec(); f.width = flow->width; f.height = flow->height;
+  if (flow) { f.header.stamp = mod_host::Time(flow->header.stamp.sec, flow->header.stamp.nsec); f.width = flow->width; f.height = flow->height;
               f.data = reinterpret_cast<const float *>(flow->data.data()); }
   if (motion) { t.translation[0] = motion->translation.x; t.translation[1] = motion->translation.y; t.translation[2] = motion->translation.z;
                 t.rotation[0] = motion->rotation.x; t.rotation[1] = motion->rotation.y; t.rotation[2] = motion->rotation.z; t.rotation[3] = motion->rotation.w; }

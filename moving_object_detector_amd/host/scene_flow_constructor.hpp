@@ -55,7 +55,7 @@ class SceneFlowConstructor {
       for (int i = 0; i < 4; i++) tf.q[i] = transform_prev2now->rotation[i];
     }
     // time_between_frames = stamp_now - stamp_previous (scene_flow_constructor.cpp:162-164)
-    const double dt = (disparity_now && disparity_previous) ? disparity_now->header.stamp - disparity_previous->header.stamp : 0.0;
+    const double dt = (disparity_now && disparity_previous) ? mod_host::duration_sec(disparity_now->header.stamp, disparity_previous->header.stamp) : 0.0;
     const size_t n = (size_t)image_width_ * image_height_;
     if (pc_with_velocity) pc_with_velocity->data.resize(n * 32);
     if (labels) labels->resize(n);
@@ -114,7 +114,7 @@ class SceneFlowConstructor {
       for (int i = 0; i < 3; i++) tf.t[i] = transform_prev2now->translation[i];
       for (int i = 0; i < 4; i++) tf.q[i] = transform_prev2now->rotation[i];
     }
-    const double dt = (disparity_now && have_stamp_) ? disparity_now->header.stamp - previous_stamp_ : 0.0;
+    const double dt = (disparity_now && have_stamp_) ? mod_host::duration_sec(disparity_now->header.stamp, previous_stamp_) : 0.0;
     const size_t n = (size_t)image_width_ * image_height_;
     int32_t ticket = -1;
     int rc = MOD_SKIP_NO_DISPARITY_NOW;
@@ -182,7 +182,7 @@ class SceneFlowConstructor {
   Pending pending_[MOD_PIPELINE_DEPTH];
   int next_slot_ = 0;
   bool have_stamp_ = false, have_parked_ = false;
-  double previous_stamp_ = 0.0;
+  mod_host::Time previous_stamp_;
   std::vector<float> parked_;
 
   ModParams currentParams() {

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../moving_object_detector_amd/host/clusterer_nodelet.hpp"
+#include "../../moving_object_detector_amd/host/ros_wire.hpp"
 #include "../../moving_object_detector_amd/host/scene_flow_constructor.hpp"
 
 template <class T>
@@ -59,7 +60,9 @@ int main(int argc, char **argv) {
   prev.f = now.f = (float)cam[8]; prev.T = now.T = (float)cam[9];
   prev.min_disparity = now.min_disparity = (float)cam[10]; prev.max_disparity = now.max_disparity = (float)cam[11];
   prev.data = d_prev.data(); now.data = d_now.data();
-  prev.header.stamp = 100.0; now.header.stamp = 100.0 + tq[7];
+  // stamps as a ROS driver produces them: (sec, nsec); the interval reaches the kernels as ros::Duration::toSec() forms it
+  prev.header.stamp = mod_host::Time(100, 250000000u);
+  now.header.stamp = mod_host::Time::fromSec(prev.header.stamp.toSec() + tq[7]);
   constructor.setCameraInfo(info, now);
 
   mod_host::FlowImage fl;
@@ -79,8 +82,19 @@ int main(int argc, char **argv) {
   const bool pub2 = constructor.stereoCallback(&now, &fl, nullptr, &dummy, nullptr);
   if (pub0 || !pub1 || pub2) { fprintf(stderr, "publish pattern wrong: %d %d %d\n", pub0, pub1, pub2); return 5; }
 
+  // the two nodes talk through the ~scene_flow topic: the cloud crosses it in ROS-1 wire format (host/ros_wire.hpp)
+  const ros_wire::Bytes on_the_wire = ros_wire::serialize(cloud);
+  mod_host::PointCloud2 received;
+  ros_wire::deserialize(on_the_wire.data(), on_the_wire.size(), received);
+  if (received.data != cloud.data || received.header.frame_id != cloud.header.frame_id) { fprintf(stderr, "cloud changed on the wire\n"); return 14; }
   std::vector<int32_t> cluster_map;
-  clusterer.dataCB(cloud, &objs_cluster, &cluster_map);
+  clusterer.dataCB(received, &objs_cluster, &cluster_map);
+  {   // and the result leaves as a serialised MovingObjectArray
+    const ros_wire::Bytes out = ros_wire::serialize(objs_cluster);
+    mod_host::MovingObjectArray echoed;
+    ros_wire::deserialize(out.data(), out.size(), echoed);
+    if (echoed.moving_object_array.size() != objs_cluster.moving_object_array.size()) { fprintf(stderr, "objects changed on the wire\n"); return 15; }
+  }
   if (objs_cluster.moving_object_array.size() != objs_fused.moving_object_array.size()) { fprintf(stderr, "object count differs\n"); return 6; }
   if (objs_cluster.header.frame_id != "left_camera") { fprintf(stderr, "header not propagated\n"); return 7; }
 
@@ -96,7 +110,7 @@ int main(int argc, char **argv) {
     const int t1 = piped.submit(&now, &fl, &tf, &c1, &o1);
     const int t2 = piped.submit(&now, &fl, nullptr, &c2, nullptr);
     mod_host::DisparityImage later = now;
-    later.header.stamp = now.header.stamp + tq[7];
+    later.header.stamp = mod_host::Time::fromSec(now.header.stamp.toSec() + tq[7]);
     const int t3 = piped.submit(&later, &fl, &tf, &c3, &o3);        // previous = `now` (parked by the skipped frame)
     if (t0 != -1 || t1 < 0 || t2 != -1 || t3 < 0) { fprintf(stderr, "ticket pattern wrong: %d %d %d %d\n", t0, t1, t2, t3); return 8; }
     piped.collect(t1);

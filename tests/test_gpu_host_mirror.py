@@ -29,17 +29,15 @@ def test_host_mirror_matches_golden(path, tmp_path):
     assert r.returncode == 0, r.stderr
     H, W = g["d_now"].shape
     cloud = np.fromfile(d + "/cloud.bin", np.float32).reshape(H, W, 8)
-    # dt reaches the library as (100 + dt) - 100: only exact when that round trip is; the fixtures use dt = 0.1
-    dt_seen = (100.0 + float(np.asarray(g["dt"]).item())) - 100.0
-    if dt_seen == float(np.asarray(g["dt"]).item()):
-        for j, k in zip((0, 1, 2, 4, 5, 6), PLANES):
-            assert bits_equal(cloud[..., j], g[k]), k
-    else:
-        for j, k in zip((0, 1, 2), PLANES[:3]):
-            assert bits_equal(cloud[..., j], g[k]), k
-        a, b = cloud[..., 4], g["vx"]
-        m = ~np.isnan(b)
-        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.allclose(a[m], b[m], rtol=1e-6, atol=0)
+    # dt reaches the library the way ros::Duration::toSec() forms it from (sec, nsec) stamps: exact for the fixtures' dt = 0.1
+    dt = float(np.asarray(g["dt"]).item())
+    nsec = int(np.floor((100.25 + dt - np.floor(100.25 + dt)) * 1e9 + 0.5)) - 250000000
+    sec = int(np.floor(100.25 + dt)) - 100
+    if nsec < 0:
+        sec, nsec = sec - 1, nsec + 1000000000
+    assert float(sec) + 1e-9 * float(nsec) == dt, "fixture dt must survive the (sec, nsec) round trip"
+    for j, k in zip((0, 1, 2, 4, 5, 6), PLANES):
+        assert bits_equal(cloud[..., j], g[k]), k
     labels = np.fromfile(d + "/labels.i32", np.int32).reshape(H, W)
     assert np.array_equal(labels, g["labels"])
     objs = np.fromfile(d + "/objects.f64", np.float64).reshape(-1, 14)
