@@ -180,7 +180,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __shared__ int s_any, s_nreq, s_nslots;
   __shared__ CompRec srec[kSlots];
   __shared__ int sroot[kSlots];
-  const int lane = threadIdx.x, w = threadIdx.y, tid = w * 64 + lane;
+  // threadIdx.y is the wave index: the same in all 64 lanes, but it arrives in a vector register — as a scalar, every row
+  // index derived from it stays on the scalar unit
+  const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane((int)threadIdx.y), tid = w * 64 + lane;
   const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
   const int MW = c.mask_words, n = c.n;
   const size_t N = (size_t)c.W * c.H;
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   constexpr int RPW = TH / NW;
   __shared__ int nlmap[TH * 64];                     // per tile-root cell: new label of its component (or -1)
   __shared__ int lcount[TH * 64];                    // per tile-root cell: member count, then base slot of its members
-  const int wi = blockIdx.x, f = blockIdx.z, lane = threadIdx.x, w = threadIdx.y;
+  const int wi = blockIdx.x, f = blockIdx.z, lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
   const size_t tidx = (size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi;
   const size_t N = (size_t)c.W * c.H;
   const size_t fN = (size_t)f * N;
