@@ -20,6 +20,8 @@ while time.time() < t_end:
     W = int(rng.choice([64, 100, 131, 160, 257, 320, 500, 640]))
     H = int(rng.choice([17, 48, 67, 96, 120, 240, 333]))
     F = int(rng.choice([1, 2, 3, 5]))
+    if it % 50 == 0:                                   # now and then a full-size frame (BASELINE.json's sizes)
+        W, H, F = [(1280, 720, 2), (1920, 1080, 1), (1242, 376, 3)][(it // 50) % 3]
     seed = int(rng.integers(0, 1 << 30))
     cam, batch = synth.make_batch(W, H, F, seed=seed)
     prm = synth.Params(dynamic_flow_diff=int(rng.choice([1, 2, 5, 8])), cluster_size=int(rng.choice([1, 5, 40, 200, 2500])),
