@@ -13,14 +13,18 @@
 // survivors of the size filter are numbered by ascending first_edge_key = the smallest raster index of a member that
 // has an up-left edge (that is where the serial scan creates the component's first — hence smallest — label).
 //
-// GPU formulation
-//   k_ccl_tile    one workgroup per 64 x TH tile + n-pixel halo: masked depth + parents live in LDS; rows are pre-linked
-//                 into runs with wave ballots (no atomics), the remaining window edges are united with LDS atomicMin
-//                 hooks (one per distinct pair per wave); the tile's components leave as atomicMin hooks on the HBM parent
-//                 plane (interior pixels AND the halo pixels they reach) + one partial statistics record per tile root.
-//   k_ccl_flatten root per pixel; tile-local records are folded into their global root's record; roots are listed.
-//   k_select      size filter + ordering by first_edge_key (the reference's numbering) + bbox/centre.
-//   k_relabel     final labels + per-cluster member segments; k_median: radix select of the median-||v|| member.
+// GPU formulation (one launcher per stage, include/mod_sf.h MOD_STAGE_*)
+//   k_ccl_tile     one workgroup per 64 x 16 tile + n-pixel halo (up / left): masked depth + parents live in LDS; rows are
+//                  pre-linked into runs with wave ballots, vertically with one union per run pair, the remaining window edges
+//                  are united with LDS atomicMin hooks; interior pixels publish parent[p] = tile root with plain stores, halo
+//                  pixels that were reached leave link requests; one partial statistics record per tile root.
+//   k_ccl_link     requests -> unions between tile roots (device-scope atomicMin hooks), one wave per tile.
+//   k_ccl_merge    every tile root finds its final root, folds its record into it; final roots are listed.
+//   k_select       size filter + ordering by first_edge_key (the reference's numbering) + bbox / centre; cluster work list.
+//   k_final        labels plane + per-cluster member lists (||v|| bits, pixel).
+//   k_median       exact selection of the member at size/2 by ||v|| (norms held in registers, LDS histogram rounds);
+//   k_median_ties  replay of libstdc++'s introsort for clusters whose median ties between different vectors;
+//   k_finalize     object ids over the accepted clusters.
 #include "mod_launch.h"
 #include <algorithm>
 #include <cstdlib>
