@@ -282,7 +282,69 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   }
 }
 
-// Scalar kernel for widths that are not a multiple of 4: thread = 1 pixel, wave = 64 px of one row.
+// Even widths that are not a multiple of 4 (the reference's own working resolution is 1242 x 376, detect_with_zed.launch:10):
+// rows are 8-byte aligned, so thread = 2 consecutive pixels (float2 loads / stores, one float4 of flow), wave = 128 px.
+__global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
+  const int lane = threadIdx.x;
+  const int x0 = (blockIdx.x * 64 + lane) * 2;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int f = blockIdx.z;
+  const bool inb = (x0 < c.W) && (y < c.H);
+  const size_t fN = (size_t)f * ((size_t)c.W * c.H);
+  const uint32_t pix = (uint32_t)y * (uint32_t)c.W + (uint32_t)x0;
+  const uint32_t o4 = pix * 4u, o8 = pix * 8u;
+  const FrameConst fc = a.fc[f];
+  uint32_t two = 0;
+  if (inb) {
+    const float *dprev_f = a.dprev + fN;
+    const float2 dn = ld<float2>(a.dnow + fN, o4);
+    const float2 dp = ld<float2>(dprev_f, o4);
+    const float4 fl = ld<float4>(a.flow + 2 * fN, o8);
+    const double ry = c.rayy[y];
+    const double2 rx = ld<double2>(c.rayx, (uint32_t)x0 * 8u);
+    Px p0, p1;
+    PxState s0, s1;
+    sf_stage1(c, fc, x0 + 0, y, dn.x, dp.x, fl.x, fl.y, rx.x, ry, p0, s0);
+    sf_stage1(c, fc, x0 + 1, y, dn.y, dp.y, fl.z, fl.w, rx.y, ry, p1, s1);
+    const uint32_t W = (uint32_t)c.W;
+    const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
+    const float g1 = ld<float>(dprev_f, ((uint32_t)s1.py * W + (uint32_t)s1.px) * 4u);
+    const double ax0 = ld<double>(c.rayx, (uint32_t)s0.px * 8u), ax1 = ld<double>(c.rayx, (uint32_t)s1.px * 8u);
+    const double ay0 = ld<double>(c.rayy, (uint32_t)s0.py * 8u), ay1 = ld<double>(c.rayy, (uint32_t)s1.py * 8u);
+    PxWarp w0, w1;
+    sf_stage2a(c, fc, s0, g0, ax0, ay0, p0, w0);
+    sf_stage2a(c, fc, s1, g1, ax1, ay1, p1, w1);
+    if (__any(w0.todo | w1.todo)) {
+      sf_stage2b(c, fc, s0, w0, p0);
+      sf_stage2b(c, fc, s1, w1, p1);
+    }
+    st(a.x + fN, o4, make_float2(p0.x, p1.x));
+    st(a.y + fN, o4, make_float2(p0.y, p1.y));
+    st(a.z + fN, o4, make_float2(p0.z, p1.z));
+    st(a.vx + fN, o4, make_float2(p0.vx, p1.vx));
+    st(a.vy + fN, o4, make_float2(p0.vy, p1.vy));
+    st(a.vz + fN, o4, make_float2(p0.vz, p1.vz));
+    if (a.aos) {
+      float4 *q = a.aos + 2 * fN;
+      const uint32_t o32 = pix * 32u;
+      st(q, o32, make_float4(p0.x, p0.y, p0.z, 0.f)); st(q, o32 + 16u, make_float4(p0.vx, p0.vy, p0.vz, 0.f));
+      st(q, o32 + 32u, make_float4(p1.x, p1.y, p1.z, 0.f)); st(q, o32 + 48u, make_float4(p1.vx, p1.vy, p1.vz, 0.f));
+    }
+    if (a.depth) st(a.depth + fN, o4, make_float2(p0.depth, p1.depth));
+    if (a.sflow) st(a.sflow + 2 * fN, o8, make_float4(p0.s0, p0.s1, p1.s0, p1.s1));
+    two = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u);
+  }
+  if (a.mask) {   // wave-uniform branch; lanes 0..31 build word 2*blockIdx.x, lanes 32..63 the next one
+    uint32_t v = two << (2 * (lane & 15));
+    v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
+    const uint32_t hi = __shfl_down(v, 16);
+    const int word = blockIdx.x * 2 + (lane >> 5);
+    if ((lane & 31) == 0 && y < c.H && word < c.mask_words)
+      a.mask[((size_t)f * c.H + y) * c.mask_words + word] = (uint64_t)v | ((uint64_t)hi << 32);
+  }
+}
+
+// Scalar kernel for odd widths: thread = 1 pixel, wave = 64 px of one row.
 __global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) {
   const int lane = threadIdx.x;
   const int x = blockIdx.x * 64 + lane;
@@ -347,6 +409,9 @@ void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t
   if ((c.W & 3) == 0) {
     dim3 grid((c.W / 4 + 63) / 64, (c.H + 3) / 4, frames);
     hipLaunchKernelGGL(k_scene_flow_v4, grid, block, 0, s, c, a);
+  } else if ((c.W & 1) == 0) {
+    dim3 grid((c.W / 2 + 63) / 64, (c.H + 3) / 4, frames);
+    hipLaunchKernelGGL(k_scene_flow_v2, grid, block, 0, s, c, a);
   } else {
     dim3 grid((c.W + 63) / 64, (c.H + 3) / 4, frames);
     hipLaunchKernelGGL(k_scene_flow_v1, grid, block, 0, s, c, a);

@@ -28,7 +28,7 @@ def test_hostile_inputs(oracle, seed):
     from moving_object_detector_amd import synth
     from moving_object_detector_amd.pipeline import Context
     rng = np.random.default_rng(1000 + seed)
-    W, H = (132, 70) if seed % 2 == 0 else (131, 67)       # vector kernel and scalar kernel (W % 4 != 0)
+    W, H = [(132, 70), (131, 67), (130, 69)][seed % 3]      # 4 px / thread, 1 px / thread (odd width), 2 px / thread (W % 4 == 2)
     cam = synth.make_camera(W, H)
     cam.fx, cam.fy = float(rng.uniform(50, 900)), float(rng.uniform(50, 900))
     cam.cx, cam.cy = float(rng.uniform(0, W)), float(rng.uniform(0, H))

@@ -17,7 +17,7 @@ t_end = time.time() + budget
 it = 0
 while time.time() < t_end:
     it += 1
-    W = int(rng.choice([64, 100, 131, 160, 257, 320, 500, 640]))
+    W = int(rng.choice([64, 100, 131, 160, 250, 257, 320, 386, 500, 640]))
     H = int(rng.choice([17, 48, 67, 96, 120, 240, 333]))
     F = int(rng.choice([1, 2, 3, 5]))
     if it % 50 == 0:                                   # now and then a full-size frame (BASELINE.json's sizes)
