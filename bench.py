@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic pairs generated per GPU (tiled to --frames)")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--camera", default="zed", choices=["zed", "kitti"], help="synthetic camera: ZED-like (config 2) or KITTI-style (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU (bounded sample)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -123,12 +124,12 @@ def main():
     # rank 0 owns the camera + dynamic_reconfigure parameters (reference defaults) and broadcasts them over RCCL
     cam_s = prm_s = None
     if rank == 0:
-        cam_s = capi.camera_struct(synth.make_camera(W, H))
+        cam_s = capi.camera_struct(synth.make_camera(W, H, args.camera))
         prm_s = capi.params_struct(synth.Params())
     cam_s, prm_s = mdist.broadcast_config(cam_s, prm_s, src=0, device=dev if args.backend == "nccl" else None)
 
     # synthetic pairs of this rank's shard (distinct seeds per rank), tiled to F frames at distinct HBM addresses
-    cam, host = synth.make_batch(W, H, G, seed=0, first_frame=rank * G)
+    cam, host = synth.make_batch(W, H, G, seed=0, first_frame=rank * G, camera=args.camera)
     idx = [i % G for i in range(F)]
     d_now = torch.from_numpy(host["disparity_now"]).to(dev)[idx].contiguous()
     d_prev = torch.from_numpy(host["disparity_prev"]).to(dev)[idx].contiguous()
@@ -233,7 +234,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_frame": 1e3 * elapsed / (args.steps * F), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} synthetic sequence, scene-flow + cluster kernels only (disparity/flow precomputed, "
+            "config": {"workload": f"{W}x{H} synthetic sequence ({args.camera}-style camera), scene-flow + cluster kernels only (disparity/flow precomputed, "
                                    f"HBM-resident), reference default parameters",
                        "frames_per_step_per_gpu": F, "distinct_frames_per_gpu": G, "sharding": f"frames x{world}",
                        "collective": "one RCCL broadcast of the intrinsics/params block before the timed region"},

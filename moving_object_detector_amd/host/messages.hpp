@@ -56,6 +56,37 @@ struct FlowImage { Header header; int width = 0, height = 0; const float *data =
 // geometry_msgs/Transform
 struct Transform { double translation[3] = {0, 0, 0}; double rotation[4] = {0, 0, 0, 1}; /* x y z w */ };
 
+// The libviso2 hand-off (scene_flow_constructor.cpp:232-249): VisualOdometryStereo::getMotion() returns the 4x4 motion of the
+// left camera from the previous to the current frame; the reference wraps it as tf2::Transform(Matrix3x3, Vector3) and stores
+// tf2::toMsg() of it, i.e. the rotation goes through tf2::Matrix3x3::getRotation() (geometry2 0.6.x, LinearMath/Matrix3x3.h —
+// not vendored by the reference; restated here, all in double) before construct() rebuilds a matrix from that quaternion.
+// Feeding the kernels anything but this quaternion (e.g. the matrix itself) would differ from the reference in the last bits.
+inline Transform transform_from_motion(const double m[4][4]) {
+  Transform t;
+  for (int i = 0; i < 3; i++) t.translation[i] = m[i][3];
+  double q[4];
+  const double trace = m[0][0] + m[1][1] + m[2][2];
+  if (trace > 0.0) {
+    double s = std::sqrt(trace + 1.0);
+    q[3] = s * 0.5;
+    s = 0.5 / s;
+    q[0] = (m[2][1] - m[1][2]) * s;
+    q[1] = (m[0][2] - m[2][0]) * s;
+    q[2] = (m[1][0] - m[0][1]) * s;
+  } else {
+    const int i = m[0][0] < m[1][1] ? (m[1][1] < m[2][2] ? 2 : 1) : (m[0][0] < m[2][2] ? 2 : 0);
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    double s = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+    q[i] = s * 0.5;
+    s = 0.5 / s;
+    q[3] = (m[k][j] - m[j][k]) * s;
+    q[j] = (m[j][i] + m[i][j]) * s;
+    q[k] = (m[k][i] + m[i][k]) * s;
+  }
+  for (int i = 0; i < 4; i++) t.rotation[i] = q[i];     // x y z w
+  return t;
+}
+
 // sensor_msgs/PointCloud2 carrying pcl::PointXYZVelocity records (point_step 32; x@0 y@4 z@8 vx@16 vy@20 vz@24)
 struct PointCloud2 {
   Header header;

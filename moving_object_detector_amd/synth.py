@@ -61,7 +61,16 @@ class Frame:
     meta: dict = field(default_factory=dict)
 
 
-def make_camera(width: int, height: int) -> Camera:
+def make_camera(width: int, height: int, style: str = "zed") -> Camera:
+    """style "zed": the ZED-like cameras of SURVEY.md §8(d); "kitti": the KITTI-style variant named there (fx = fy = 721.5377,
+    cx = 609.5593, baseline 0.5372 m at the native 1242 x 375, scaled to the requested size) — BASELINE.json config 3."""
+    if style == "kitti":
+        sx, sy = width / 1242.0, height / 375.0
+        fx = fy = 721.5377 * sx
+        return Camera(width, height, fx, fy, 609.5593 * sx, 172.854 * sy, 0.0, 0.0, np.float32(fx), np.float32(0.5372),
+                      np.float32(0.0), np.float32(128.0))
+    if style != "zed":
+        raise ValueError(f"unknown camera style {style!r}")
     if (width, height) in _CAMERAS:
         fx, fy, cx, cy, base = _CAMERAS[(width, height)]
     else:  # any other size: scale the 1280x720 ZED-like camera
@@ -112,14 +121,14 @@ def _background_depth(cam: Camera, origin: np.ndarray, R: np.ndarray, xs: np.nda
 
 def make_frame(width: int = 1280, height: int = 720, seed: int = 0, frame: int = 0, *, n_objects: int = 6,
                n_small: int = 2, n_isolated: int = 24, dt: float = 0.1, quantize: bool = True,
-               invalid: bool = True) -> tuple[Camera, Frame]:
+               invalid: bool = True, camera: str = "zed") -> tuple[Camera, Frame]:
     """One stereo pair (now + previous disparity), its flow and ego-motion.
 
     Object depth 4-9 m, speed 1-2 m/s and dt = 0.1 s (the KITTI-style value of SURVEY.md §8(d)) are chosen so that the
     image-plane residual exceeds the reference's default ``dynamic_flow_diff`` of 5 px; slower / farther objects are
     (faithfully) not detected by the reference at its defaults.
     """
-    cam = make_camera(width, height)
+    cam = make_camera(width, height, camera)
     W, H = width, height
     rng = np.random.Generator(np.random.PCG64([0x5EED0000 + seed, frame]))
     sc = W / 1280.0                                        # size scale relative to the 720p layout
@@ -234,7 +243,7 @@ def make_frame(width: int = 1280, height: int = 720, seed: int = 0, frame: int =
 
 def make_batch(width: int, height: int, frames: int, seed: int = 0, first_frame: int = 0, **kw):
     """`frames` independent pairs stacked: disparity_now/prev (F,H,W), flow (F,H,W,2), t (F,3), q (F,4), dt (F,)."""
-    cam = make_camera(width, height)
+    cam = make_camera(width, height, kw.get("camera", "zed"))
     dn = np.empty((frames, height, width), np.float32)
     dp = np.empty((frames, height, width), np.float32)
     fl = np.empty((frames, height, width, 2), np.float32)

@@ -2,6 +2,7 @@
 // rejects.  Also pins ros::Time / ros::Duration arithmetic of host/messages.hpp.  Prints "ok" and exits 0.
 #include "../../moving_object_detector_amd/host/ros_wire.hpp"
 
+#include <cmath>
 #include <cstdio>
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
@@ -108,6 +109,48 @@ int main() {
   Transform tb;
   ros_wire::deserialize(g4.data(), g4.size(), tb);
   CHECK(memcmp(&tf, &tb, sizeof(tf)) == 0);
+  // ---- viso2 motion matrix -> geometry_msgs/Transform (tf2::Matrix3x3::getRotation restated) ----
+  {
+    auto rot = [](const double q[4], double m[4][4]) {       // rotation matrix of a unit quaternion x y z w
+      const double x = q[0], y = q[1], z = q[2], w = q[3];
+      const double r[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                              {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                              {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+      for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m[i][j] = (i < 3 && j < 3) ? r[i][j] : (i == j ? 1.0 : 0.0);
+    };
+    double m[4][4];
+    const double ident[4] = {0, 0, 0, 1};
+    rot(ident, m); m[0][3] = 0.01; m[1][3] = -0.002; m[2][3] = 0.08;
+    Transform t = transform_from_motion(m);
+    CHECK(t.rotation[0] == 0 && t.rotation[1] == 0 && t.rotation[2] == 0 && t.rotation[3] == 1);
+    CHECK(t.translation[0] == 0.01 && t.translation[1] == -0.002 && t.translation[2] == 0.08);
+    // half turns have trace -1: one case per branch of the largest-diagonal selection
+    const double hx[4] = {1, 0, 0, 0}, hy[4] = {0, 1, 0, 0}, hz[4] = {0, 0, 1, 0};
+    rot(hx, m); t = transform_from_motion(m); CHECK(t.rotation[0] == 1 && t.rotation[1] == 0 && t.rotation[2] == 0 && t.rotation[3] == 0);
+    rot(hy, m); t = transform_from_motion(m); CHECK(t.rotation[0] == 0 && t.rotation[1] == 1 && t.rotation[2] == 0 && t.rotation[3] == 0);
+    rot(hz, m); t = transform_from_motion(m); CHECK(t.rotation[0] == 0 && t.rotation[1] == 0 && t.rotation[2] == 1 && t.rotation[3] == 0);
+    // small ego-motion rotations (the case on the road) and arbitrary ones come back to within rounding, up to sign
+    uint64_t st = 88172645463325252ull;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0 * 2.0 - 1.0; };
+    for (int it = 0; it < 20000; it++) {
+      double q[4] = {rnd(), rnd(), rnd(), rnd()};
+      if (it % 2) { q[0] *= 0.01; q[1] *= 0.01; q[2] *= 0.01; q[3] = 1.0; }
+      const double nrm = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      if (nrm < 1e-3) continue;
+      for (double &v : q) v /= nrm;
+      rot(q, m);
+      t = transform_from_motion(m);
+      const double sgn = (t.rotation[0] * q[0] + t.rotation[1] * q[1] + t.rotation[2] * q[2] + t.rotation[3] * q[3]) < 0 ? -1.0 : 1.0;
+      for (int i = 0; i < 4; i++) CHECK(std::fabs(sgn * t.rotation[i] - q[i]) < 1e-13);
+    }
+    // a pinned value: yaw 0.4 deg about y (the synthetic sequence's nominal ego rotation), computed by hand with the formulas above
+    const double a = 0.4 * 3.14159265358979323846 / 180.0;
+    const double qy[4] = {0, std::sin(a / 2), 0, std::cos(a / 2)};
+    rot(qy, m);
+    t = transform_from_motion(m);
+    const double tr = m[0][0] + m[1][1] + m[2][2], s0 = std::sqrt(tr + 1.0);
+    CHECK(t.rotation[3] == s0 * 0.5 && t.rotation[1] == (m[0][2] - m[2][0]) * (0.5 / s0) && t.rotation[0] == 0 && t.rotation[2] == 0);
+  }
   printf("ok\n");
   return 0;
 }

@@ -135,3 +135,13 @@ def test_dynamic_mask_is_exact_at_the_threshold():
         assert np.array_equal(bits, want), (th, int((bits != want).sum()))
         assert 0.02 < want.mean() < 0.98
         ctx.close()
+
+
+def test_kitti_style_camera(oracle):
+    """BASELINE.json config 3's data shape: KITTI-style intrinsics / baseline, dt = 0.1 s."""
+    from moving_object_detector_amd import synth
+    cam, batch = synth.make_batch(496, 150, 2, seed=17, camera="kitti")
+    assert abs(cam.fx - 721.5377 * 496 / 1242) < 1e-9 and float(cam.disp_T) == np.float32(0.5372)
+    prm = synth.Params(cluster_size=300)
+    out = _run_gpu(cam, prm, batch)
+    _check_against_oracle(oracle, cam, prm, batch, out)
