@@ -38,6 +38,49 @@ __global__ __launch_bounds__(256) void k_v0(Args a) {
   }
 }
 
+// Partial skeletons: which side of the traffic costs the bandwidth?  MODE bit 0: reads, bit 1: gather, bit 2: six writes (else one)
+template <int MODE>
+__global__ __launch_bounds__(256) void k_part(Args a) {
+  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  remap(bx, by, bz, true);
+  const int x0 = (bx * 64 + threadIdx.x) * 4, y = by * 4 + threadIdx.y;
+  if (x0 >= a.W || y >= a.H) return;
+  const size_t fN = (size_t)bz * a.W * a.H;
+  const uint32_t pix = y * a.W + x0, o4 = pix * 4, o8 = pix * 8;
+  float4 q = make_float4((float)x0, (float)y, 1.f, 2.f);
+  if (MODE & 1) {
+    const float4 dn = ld<float4>(a.dn + fN, o4), dp = ld<float4>(a.dp + fN, o4), fa = ld<float4>(a.fl + 2 * fN, o8), fb = ld<float4>(a.fl + 2 * fN, o8 + 16);
+    q = make_float4(dn.x + dp.x, fa.x + fb.x, dn.w + fa.w, dp.y + fb.y);
+  }
+  if (MODE & 2) q.w += ld<float>(a.dp + fN, ((pix ^ 64u) % (uint32_t)(a.W * a.H)) * 4u);
+  if (MODE & 4) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) st(a.o[k] + fN, o4, q);
+  } else if (q.x == 12345.678f) st(a.o[0] + fN, o4, q);   // keeps the loads alive, never true
+}
+
+// Row-interleaved output planes: one buffer, row y holds the six planes' row segments back to back (pitch = 6 W), so the six
+// stores of a wave land in one 6 x W x 4 B region instead of six regions a plane apart.  MODE as k_part.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rowil(Args a) {
+  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  remap(bx, by, bz, true);
+  const int x0 = (bx * 64 + threadIdx.x) * 4, y = by * 4 + threadIdx.y;
+  if (x0 >= a.W || y >= a.H) return;
+  const size_t fN = (size_t)bz * a.W * a.H;
+  const uint32_t pix = y * a.W + x0, o4 = pix * 4, o8 = pix * 8;
+  float4 q = make_float4((float)x0, (float)y, 1.f, 2.f);
+  if (MODE & 1) {
+    const float4 dn = ld<float4>(a.dn + fN, o4), dp = ld<float4>(a.dp + fN, o4), fa = ld<float4>(a.fl + 2 * fN, o8), fb = ld<float4>(a.fl + 2 * fN, o8 + 16);
+    q = make_float4(dn.x + dp.x, fa.x + fb.x, dn.w + fa.w, dp.y + fb.y);
+  }
+  if (MODE & 2) q.w += ld<float>(a.dp + fN, ((pix ^ 64u) % (uint32_t)(a.W * a.H)) * 4u);
+  float *base = a.o[0] + 6 * fN;                      // o[0] is allocated 6 planes long in this variant
+  const uint32_t row = ((uint32_t)y * 6u * (uint32_t)a.W + (uint32_t)x0) * 4u;
+#pragma unroll
+  for (int k = 0; k < 6; k++) st(base, row + (uint32_t)k * (uint32_t)a.W * 4u, q);
+}
+
 // V1: thread = 8 px (two float4 per plane), block 64x4 -> a wave covers 512 px of a row
 __global__ __launch_bounds__(256) void k_v1(Args a) {
   uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -129,6 +172,29 @@ int main(int argc, char **argv) {
       run(name, [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
       for (int k = 0; k < 9; k++) CK(hipFree(base[k]));
     }
+  }
+  {
+    const double all = bytes;
+    auto runp = [&](const char *name, double b, auto launch) {
+      for (int i = 0; i < 2; i++) launch();
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 10; i++) launch();
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+      printf("%-44s %8.3f ms  %6.2f us/frame  %6.0f GB/s of its own bytes\n", name, ms, 1e3 * ms / F, b / ms / 1e6);
+    };
+    (void)all;
+    runp("reads only (16 B/px)", 16.0 * FN, [&] { hipLaunchKernelGGL((k_part<1>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
+    runp("reads + gather (16 B/px)", 16.0 * FN, [&] { hipLaunchKernelGGL((k_part<3>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
+    runp("six plane writes only (24 B/px)", 24.0 * FN, [&] { hipLaunchKernelGGL((k_part<4>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
+    runp("reads + six writes, no gather (40 B/px)", 40.0 * FN, [&] { hipLaunchKernelGGL((k_part<5>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
+  }
+  {
+    Args b = a;
+    float *big; CK(hipMalloc(&big, FN * 4 * 6));
+    b.o[0] = big;
+    run("row-interleaved outputs, full traffic", [&] { hipLaunchKernelGGL((k_rowil<3>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+    CK(hipFree(big));
   }
   run("V1 64x4, 8 px/thread", [&] { hipLaunchKernelGGL(k_v1, dim3(3, 180, F), dim3(64, 4), 0, 0, a); });
   run("V2 256x1 (one row per block)", [&] { hipLaunchKernelGGL(k_v2, dim3(2, 720, F), dim3(256), 0, 0, a); });
