@@ -1132,8 +1132,13 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t N = (size_t)c.W * c.H;
   const int nwork = a.counters[7];
-  __shared__ uint32_t lkey[kTieLds], lval[kTieLds];
-  __shared__ uint16_t lA[kTieLds], lB[kTieLds];      // positions inside the LDS-resident range fit 16 bits
+  // 96 KB of LDS, used twice: while the members are laid out, as kTieLds 64-bit cell masks + kTieLds cell offsets; during the
+  // LDS part of the sort, as keys, values and two 16-bit position lists (positions inside the resident range fit 16 bits)
+  __shared__ uint64_t lraw[kTieLds + kTieLds / 2];
+  uint32_t *lkey = reinterpret_cast<uint32_t *>(&lraw[0]), *lval = lkey + kTieLds;
+  uint16_t *lA = reinterpret_cast<uint16_t *>(lval + kTieLds), *lB = lA + kTieLds;
+  uint64_t *cmask = &lraw[0];
+  uint32_t *cstart = reinterpret_cast<uint32_t *>(&lraw[kTieLds]);
   __shared__ int s_box[4];
   __shared__ TieShared sh;
   for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
@@ -1157,14 +1162,15 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     __syncthreads();
     {
       uint32_t x0 = 0xffffffffu, x1 = 0, y0 = 0xffffffffu, y1 = 0;
-      const float invW = 1.0f / (float)c.W;          // p < 2^24: (p + 0.5) / W truncates to the row exactly
+      const float invW = 1.0f / (float)c.W;          // p < 2^24: (p + 0.5) / W truncates to the row exactly (else: divide)
+      const bool small_image = N < (1u << 24);
       for (int i0 = tid; i0 < size; i0 += kTieThreads * 4) {
         uint32_t p4[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) p4[u] = Bpos[min(i0 + u * kTieThreads, size - 1)];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          const uint32_t y = (uint32_t)(((float)p4[u] + 0.5f) * invW), x = p4[u] - y * (uint32_t)c.W;
+          const uint32_t y = small_image ? (uint32_t)(((float)p4[u] + 0.5f) * invW) : p4[u] / (uint32_t)c.W, x = p4[u] - y * (uint32_t)c.W;
           x0 = x < x0 ? x : x0; x1 = x > x1 ? x : x1; y0 = y < y0 ? y : y0; y1 = y > y1 ? y : y1;
         }
       }
@@ -1175,6 +1181,65 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     TSTAMP(20)
     if (c.debug & (1 << 20)) continue;
     const int xmin = s_box[0], ymin = s_box[2], ymax = s_box[3], ncols = s_box[1] - xmin + 1;
+    // ---- members in column-major order (clusterMap2IndicesCluster's order, :97-117) ----
+    // Fast path, straight from the member list (two coalesced passes, no image reads): the bounding box is cut into cells of
+    // one column x 64 rows; pass A sets bit (row & 63) of a member's cell, a prefix over the cells in column-major order gives
+    // every cell its first slot, pass B puts member (column, row) at slot = start[cell] + popcount(mask[cell] below its bit).
+    const int nseg64 = (ymax - ymin + 64) / 64;
+    if (ncols * nseg64 <= kTieLds) {
+      const int ncell = ncols * nseg64;
+      const float invWf = 1.0f / (float)c.W;
+      for (int i = tid; i < kTieLds; i += kTieThreads) cmask[i] = 0ull;
+      __syncthreads();
+      auto cell_of = [&](uint32_t p, int &bit) {
+        const uint32_t y = (N < (1u << 24)) ? (uint32_t)(((float)p + 0.5f) * invWf) : p / (uint32_t)c.W, x = p - y * (uint32_t)c.W;
+        const int ry = (int)y - ymin;
+        bit = ry & 63;
+        return ((int)x - xmin) * nseg64 + (ry >> 6);
+      };
+      for (int i0 = tid; i0 < size; i0 += kTieThreads * 8) {
+        uint32_t p8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) p8[u] = Bpos[min(i0 + u * kTieThreads, size - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (i0 + u * kTieThreads < size) { int bit; const int cl = cell_of(p8[u], bit); atomicOr((unsigned long long *)&cmask[cl], 1ull << bit); }
+      }
+      __syncthreads();
+      TSTAMP(21)
+      {   // exclusive prefix of the cell populations; thread t owns cells 8t .. 8t+7
+        int cnt[8], tot = 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int ci2 = tid * 8 + u; cnt[u] = ci2 < ncell ? __popcll((unsigned long long)cmask[ci2]) : 0; tot += cnt[u]; }
+        int incl = tot;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) sh.cntA[wv] = incl;
+        __syncthreads();
+        if (tid == 0) { int run = 0; for (int t = 0; t < kTieThreads / 64; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; } }
+        __syncthreads();
+        int run = sh.cntA[wv] + incl - tot;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { cstart[tid * 8 + u] = (uint32_t)run; run += cnt[u]; }
+      }
+      __syncthreads();
+      for (int i0 = tid; i0 < size; i0 += kTieThreads * 8) {
+        uint32_t p8[8], k8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = min(i0 + u * kTieThreads, size - 1); p8[u] = Bpos[i]; k8[u] = Apos[i]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (i0 + u * kTieThreads < size) {
+            int bit;
+            const int cl = cell_of(p8[u], bit);
+            const int slot = (int)cstart[cl] + __popcll((unsigned long long)(cmask[cl] & ((1ull << bit) - 1ull)));
+            key[slot] = k8[u];                        // ||v|| bits as k_final computed them (norm3_f32)
+            val[slot] = p8[u];
+          }
+      }
+      __syncthreads();
+      TSTAMP(22)
+    } else {
+    // Fallback for bounding boxes with more than kTieLds cells: scan the box in the image.
     if (ncols > kTieCols) continue;                  // wider than the column table: keep the canonical pick (stays flagged)
     // ---- members in column-major order: count, prefix, fill.  The bounding box is cut into (64-column chunk, row segment)
     // work items so that all 16 waves are busy; a wave reads 4 rows of its chunk at a time (coalesced, 4-16 reads in flight).
@@ -1183,8 +1248,8 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     const int nchunks = (ncols + 63) / 64, ncp = nchunks * 64;
     const int nseg = max(1, min(8, (2 * kTieLds) / ncp));          // lkey + lval hold 2 * kTieLds ints
     const int rows = ymax - ymin + 1, segH = (rows + nseg - 1) / nseg;
-    int *cc = (int *)&lkey[0];
-    int *cc2 = (int *)&lval[0];
+    int *cc = (int *)lkey;
+    int *cc2 = (int *)lval;
     auto CC = [&](int sg, int cx) -> int & { const int i = sg * ncp + cx; return i < kTieLds ? cc[i] : cc2[i - kTieLds]; };
     for (int it = wv; it < nchunks * nseg; it += kTieThreads / 64) {
       const int ch = it % nchunks, sg = it / nchunks;
@@ -1245,6 +1310,7 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     }
     __syncthreads();
     TSTAMP(22)
+    }
     TSTAMP(23)
     if (c.debug & (1 << 22)) continue;
     if (tid == 0) { sh.first = 0; sh.last = size; sh.depth = 2 * floor_log2(size); sh.done = 0; }
@@ -1261,10 +1327,10 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
       __syncthreads();
       if (tid == 0) { sh.first = 0; sh.last = len; }
       __syncthreads();
-      tie_narrow(&lkey[0], &lval[0], &lA[0], &lB[0], want - first, 16, sh, tid);
+      tie_narrow(lkey, lval, lA, lB, want - first, 16, sh, tid);
       __syncthreads();
       if (!sh.done && tid == 0) {
-        const View v{&lkey[0], &lval[0]};
+        const View v{lkey, lval};
         insertion_sort(v, sh.first, sh.last);
         sh.answer = lval[want - first];
       }

@@ -1,5 +1,5 @@
 import ctypes as C, os, sys
-os.environ["MOD_DEBUG"] = "128"
+os.environ["MOD_DEBUG"] = "0"   # the tile kernel's phase counters (bit 128) share slots with the tie kernel's
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from moving_object_detector_amd import synth
