@@ -1017,7 +1017,7 @@ constexpr int kTieThreads = 1024, kTieCols = 2048, kTieLds = 8192;
 struct TieShared {           // control block of one workgroup of k_median_ties
   int cntA[kTieThreads / 64], cntB[kTieThreads / 64];
   int first, last, depth, m, totA, done;
-  uint32_t answer;
+  uint32_t answer, pivot;
 };
 
 // One __unguarded_partition_pivot step on [first, last) of (key, val), by the whole workgroup; updates sh.first / sh.last
@@ -1031,11 +1031,21 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
   constexpr int NW = kTieThreads / 64;
   if (tid == 0) {
     sh.depth--;
-    const View v{&key[0], &val[0]};
-    move_median_to_first(v, first, first + 1, first + (last - first) / 2, last - 1);
+    // __move_median_to_first(first, first + 1, mid, last - 1): the three keys are fetched together (one memory round trip
+    // instead of one per comparison), the comparison tree of introsort_emul::move_median_to_first picks the median's
+    // position, and the pivot's key is handed to the workgroup through LDS
+    const int ia = first + 1, ib = first + (last - first) / 2, ic = last - 1;
+    const uint32_t ka = key[ia], kb = key[ib], kc = key[ic];
+    int im;                                              // comp(x, y) = key[x] > key[y]
+    if (ka > kb) im = (kb > kc) ? ib : (ka > kc) ? ic : ia;
+    else im = (ka > kc) ? ia : (kb > kc) ? ic : ib;
+    const uint32_t km = (im == ia) ? ka : (im == ib) ? kb : kc;
+    const uint32_t kf = key[first], vf = val[first], vm = val[im];
+    key[first] = km; val[first] = vm; key[im] = kf; val[im] = vf;
+    sh.pivot = km;
   }
   __syncthreads();
-  const uint32_t pk = key[first];
+  const uint32_t pk = sh.pivot;
   // A: elements NOT before the pivot (key <= pk), ranked from the left; B: elements NOT after it (key >= pk), ranked from the
   // right.  Wave w owns one contiguous slice and reads it 64 consecutive elements at a time (4 reads in flight).
   const int lo = first + 1, L = last - lo;
