@@ -2,7 +2,7 @@
 tag=$1; ctrs=$2; kn=$3
 out=/root/repo/gpurun_out/$tag
 mkdir -p $out && cd /tmp && export TMPDIR=/tmp
-timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --distinct 4 > $out/bench.json 2> $out/err.log
+timeout -k 10 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --distinct 4 ${PMC_ARGS:-} > $out/bench.json 2> $out/err.log
 echo rc=$?
 python3 - <<PY
 import csv,glob,collections
