@@ -13,7 +13,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmod_sf.so")
+LIB_PATH = os.environ.get("MOD_SF_LIB") or os.path.join(_HERE, "libmod_sf.so")   # MOD_SF_LIB: A/B builds during development
 
 MOD_OK = 0
 MOD_SKIP_NO_DISPARITY_NOW = 1
