@@ -283,7 +283,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   for (int j = 0; j < RPW; j++) {
     const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
     const uint64_t mw = m0[rr + NMAX], mu = m0[rr + NMAX - 1];
-    if ((mw & mu) == 0 || (c.debug & 2048)) continue;                    // wave-uniform
+    if ((mw & mu) == 0 || MOD_ABLATE(c, 2048)) continue;                    // wave-uniform
     const bool v = ((mw & mu) >> lane) & 1ull;
     const bool link = v && !(fabsf(zt[me] - zt[me - PW]) > th);
     int cur = ld_relaxed(&Lt[me]), last = -1;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   for (int j = 0; j < RPW; j++) {
     const int rr = w + NW * j;
     const uint64_t mw = m0[rr + NMAX];
-    if (mw == 0 || (c.debug & 256)) continue;                           // wave-uniform
+    if (mw == 0 || MOD_ABLATE(c, 256)) continue;                           // wave-uniform
     const bool dyn = (mw >> lane) & 1ull;
     const int me = (rr + NMAX) * PW + NMAX + lane;
     const float zp = zt[me];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       }
       up = up || (vmask != 0);
       // pass 2, rare after A1-A3: unions, one window position at a time
-      if (!(c.debug & 1) && __ballot(need_any)) {
+      if (!MOD_ABLATE(c, 1) && __ballot(need_any)) {
         COUNT(10, 1)
 #pragma unroll
         for (int k = 0; k <= NMAX; k++) {
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int topcells = n * (64 + n);               // n rows x (n + 64) columns above the tile
     const int total = topcells + TH * n;             // + TH rows x n columns left of it
     uint2 *req = a.requests + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * a.req_cap;
-    for (int i0 = 0; i0 < total && !(c.debug & 1024); i0 += NW * 64) {
+    for (int i0 = 0; i0 < total && !MOD_ABLATE(c, 1024); i0 += NW * 64) {
       const int i = i0 + tid;
       bool linked = false;
       int hg = 0, rg = 0;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = w + NW * j, gy = y0 + rr;
-    if (m0[rr + NMAX] == 0 || (c.debug & 520)) continue;                // wave-uniform
+    if (m0[rr + NMAX] == 0 || MOD_ABLATE(c, 520)) continue;                // wave-uniform
     const int rg = rootg[j];
     uint32_t ox = 0, oy = 0, oz = 0, key = (uint32_t)kKeyNone;
     int slot = -1, over = -1;
@@ -778,20 +778,12 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
 // The member norms are read from HBM ONCE, into registers (kMedRegs per thread, 32 Ki members per workgroup; the tail of
 // a larger cluster is re-read per pass): every narrowing round then runs out of registers and LDS, so a cluster costs a
 // few HBM round trips instead of one per pass.  Neighbouring members have similar norms, i.e. a wave's lanes mostly hit
-// the same histogram bin: the lanes of a bin are counted with a ballot and added by one lane (hist_add).
-constexpr int kMedThreads = 1024, kMedBins = 2048, kMedRegs = 32, kHistAgg = 0;
+// the same histogram bin; the LDS unit serialises those adds itself.
+constexpr int kMedThreads = 1024, kMedBins = 2048, kMedRegs = 32;
 
-// hist[bin] += 1 for every lane with `on`; lanes that share a bin are aggregated, a few rounds, then plain atomics
-__device__ __forceinline__ void hist_add(uint32_t *hist, bool on, uint32_t bin, int lane) {
-  uint64_t act = __ballot(on);
-  for (int it = 0; it < kHistAgg && act; it++) {     // wave-uniform
-    const int lead = __ffsll((unsigned long long)act) - 1;
-    const uint32_t b0 = (uint32_t)__shfl((int)bin, lead);
-    const uint64_t same = __ballot(on && bin == b0);
-    if (lane == lead) atomicAdd(&hist[b0], (uint32_t)__popcll((unsigned long long)same));
-    on = on && bin != b0;
-    act &= ~same;
-  }
+// hist[bin] += 1 for every lane with `on`.  (Aggregating the lanes of a bin with ballots first was measured: slower than the
+// LDS unit's own handling of same-address atomics.)
+__device__ __forceinline__ void hist_add(uint32_t *hist, bool on, uint32_t bin, int) {
   if (on) atomicAdd(&hist[bin], 1u);
 }
 
@@ -1189,7 +1181,7 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     }
     __syncthreads();
     TSTAMP(20)
-    if (c.debug & (1 << 20)) continue;
+    if (MOD_ABLATE(c, 1 << 20)) continue;
     const int xmin = s_box[0], ymin = s_box[2], ymax = s_box[3], ncols = s_box[1] - xmin + 1;
     // ---- members in column-major order (clusterMap2IndicesCluster's order, :97-117) ----
     // Fast path, straight from the member list (two coalesced passes, no image reads): the bounding box is cut into cells of
@@ -1277,7 +1269,7 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     }
     __syncthreads();
     TSTAMP(21)
-    if (c.debug & (1 << 21)) continue;
+    if (MOD_ABLATE(c, 1 << 21)) continue;
     // exclusive prefix in column-major order: columns left to right, inside a column the segments top to bottom
     {
       int tot0 = 0, tot1 = 0;                                        // thread t owns columns 2t and 2t+1
@@ -1322,14 +1314,14 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     TSTAMP(22)
     }
     TSTAMP(23)
-    if (c.debug & (1 << 22)) continue;
+    if (MOD_ABLATE(c, 1 << 22)) continue;
     if (tid == 0) { sh.first = 0; sh.last = size; sh.depth = 2 * floor_log2(size); sh.done = 0; }
     __syncthreads();
     // ---- introsort, only along the range that holds position size/2: in HBM while the range is long, then in LDS ----
     const int want = size / 2;
     tie_narrow(key, val, Apos, Bpos, want, kTieLds, sh, tid);
     TSTAMP(24)
-    if (c.debug & (1 << 23)) continue;
+    if (MOD_ABLATE(c, 1 << 23)) continue;
     __syncthreads();
     if (!sh.done) {
       const int first = sh.first, len = sh.last - first;

@@ -6,6 +6,15 @@
 
 #define MOD_WAVE 64
 
+// Ablation switches for timing experiments (tools/ablate.sh): compiled in only with `make ABLATE=1`; a product build carries
+// none of them.  MOD_ABLATE(c, bits) is true when the diagnostic build runs with one of `bits` set in MOD_DEBUG — the results
+// are then wrong on purpose (a phase is skipped).
+#ifdef MOD_ABLATION
+#define MOD_ABLATE(c, bits) (((c).debug & (bits)) != 0)
+#else
+#define MOD_ABLATE(c, bits) false
+#endif
+
 // Camera / parameter block as the kernels see it.  Everything that the reference computes per pixel but that only
 // depends on the camera (F32 product f*T, pixel rays, threshold conversions) is computed ONCE on the host with the same
 // IEEE operations and uploaded, so the per-pixel results stay bit-identical to the reference expressions.
@@ -14,7 +23,7 @@ struct DevCam {
   int32_t mask_words;      // ceil(W/64)
   int32_t n;               // neighbor_distance
   int32_t cluster_size;
-  int32_t debug;           // MOD_DEBUG experiment bits (0 in production): timing ablations only, results become wrong
+  int32_t debug;           // MOD_DEBUG bits of the diagnostic builds (ABLATE=1 / PHASE_COUNTERS=1); ignored by a product build
   float fT;                // F32(f * T)                       disparity_image_processor.cpp:44
   float dmin, dmax;        // min/max_disparity                disparity_image_processor.cpp:25-27
   float flow_th_sq;        // smallest F32 a with sqrtf(a) >= (float)dynamic_flow_diff   scene_flow_constructor.cpp:198

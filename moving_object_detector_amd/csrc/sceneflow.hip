@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   {
     const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
-    if ((total & 7u) == 0u && !(c.debug & 64)) {
+    if ((total & 7u) == 0u && !MOD_ABLATE(c, 64)) {
       const uint32_t lin = bx + gridDim.x * (by + gridDim.y * bz);
       const uint32_t m = (lin & 7u) * (total >> 3) + (lin >> 3);
       bx = m % gridDim.x;
