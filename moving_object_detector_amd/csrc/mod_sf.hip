@@ -284,8 +284,9 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   return MOD_OK;
 }
 
+// allocates unless *p already points at a buffer (lazily built buffer sets can be resumed after a failed attempt without leaking)
 template <class T>
-hipError_t dalloc(T **p, size_t count) { return hipMalloc((void **)p, count * sizeof(T)); }
+hipError_t dalloc(T **p, size_t count) { return *p ? hipSuccess : hipMalloc((void **)p, count * sizeof(T)); }
 
 }  // namespace
 
@@ -493,13 +494,13 @@ int mod_unpack_cloud_dev(ModContext *c, int32_t frames, const void *aos, const M
 // ---- host-pointer convenience --------------------------------------------------------------------------------------
 static int ensure_host_staging(ModContext *c) {
   Buffers &b = c->b;
-  if (b.h_dnow) return MOD_OK;
+  if (b.h_objects) return MOD_OK;                    // the last buffer of the set exists: all do
   const size_t N = c->maxN;
   HIP_TRY(c, dalloc(&b.h_dnow, N));
   HIP_TRY(c, dalloc(&b.h_dprev, N));
   HIP_TRY(c, dalloc(&b.h_flow, 2 * N));
   HIP_TRY(c, dalloc(&b.h_planes, 6 * N));
-  HIP_TRY(c, hipMalloc(&b.h_aos, 32 * N));
+  if (!b.h_aos) HIP_TRY(c, hipMalloc(&b.h_aos, 32 * N));
   HIP_TRY(c, dalloc(&b.h_labels, N));
   HIP_TRY(c, dalloc(&b.h_nobj, 8));
   HIP_TRY(c, dalloc(&b.h_objects, (size_t)c->max_objects));
@@ -589,22 +590,22 @@ static int ensure_pipe(ModContext *c) {
   ModContext::Pipe &p = c->pipe;
   if (p.ready) return MOD_OK;
   const size_t N = c->maxN;
-  HIP_TRY(c, hipStreamCreateWithFlags(&p.h2d, hipStreamNonBlocking));
-  HIP_TRY(c, hipStreamCreateWithFlags(&p.d2h, hipStreamNonBlocking));
+  if (!p.h2d) HIP_TRY(c, hipStreamCreateWithFlags(&p.h2d, hipStreamNonBlocking));
+  if (!p.d2h) HIP_TRY(c, hipStreamCreateWithFlags(&p.d2h, hipStreamNonBlocking));
   for (int i = 0; i <= MOD_PIPELINE_DEPTH; i++) HIP_TRY(c, dalloc(&p.dnow[i], N));
   for (int i = 0; i < MOD_PIPELINE_DEPTH; i++) {
     HIP_TRY(c, dalloc(&p.dprev[i], N));
     HIP_TRY(c, dalloc(&p.flow[i], 2 * N));
     HIP_TRY(c, dalloc(&p.planes[i], 6 * N));
-    HIP_TRY(c, hipMalloc(&p.aos[i], 32 * N));
+    if (!p.aos[i]) HIP_TRY(c, hipMalloc(&p.aos[i], 32 * N));
     HIP_TRY(c, dalloc(&p.labels[i], N));
     HIP_TRY(c, dalloc(&p.nobj[i], 8));
     HIP_TRY(c, dalloc(&p.objects[i], (size_t)c->max_objects));
-    HIP_TRY(c, hipHostMalloc((void **)&p.h_n[i], 64, hipHostMallocDefault));
-    HIP_TRY(c, hipHostMalloc((void **)&p.h_obj[i], sizeof(ModObject) * (size_t)c->max_objects, hipHostMallocDefault));
-    HIP_TRY(c, hipEventCreateWithFlags(&p.ev_in[i], hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&p.ev_done[i], hipEventDisableTiming));
-    HIP_TRY(c, hipEventCreateWithFlags(&p.ev_out[i], hipEventDisableTiming));
+    if (!p.h_n[i]) HIP_TRY(c, hipHostMalloc((void **)&p.h_n[i], 64, hipHostMallocDefault));
+    if (!p.h_obj[i]) HIP_TRY(c, hipHostMalloc((void **)&p.h_obj[i], sizeof(ModObject) * (size_t)c->max_objects, hipHostMallocDefault));
+    if (!p.ev_in[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_in[i], hipEventDisableTiming));
+    if (!p.ev_done[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_done[i], hipEventDisableTiming));
+    if (!p.ev_out[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_out[i], hipEventDisableTiming));
   }
   p.ready = true;
   return MOD_OK;
