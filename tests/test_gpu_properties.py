@@ -97,3 +97,39 @@ def test_full_size_frame_matches_oracle_1920x1080(oracle):
     prm = synth.Params()
     out = _run_gpu(cam, prm, batch)
     _check_against_oracle(oracle, cam, prm, batch, out)
+
+
+def test_stage_timers_follow_the_stage_mask():
+    """mod_set_profiling(stage_mask): only the selected kernel groups are bracketed; results do not depend on it."""
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+    W, H, F = 320, 240, 2
+    cam, batch = synth.make_batch(W, H, F, seed=2)
+    ctx = Context(W, H, max_frames=F)
+    ctx.set_camera(cam)
+    ctx.set_params(synth.Params(cluster_size=200))
+    ws = ctx.workspace(F)
+    dev = ctx.device
+    b = ctx.make_batch(torch.from_numpy(batch["disparity_now"]).to(dev), torch.from_numpy(batch["disparity_prev"]).to(dev),
+                       torch.from_numpy(batch["flow"]).to(dev), batch["t"], batch["q"], batch["dt"])
+    assert ctx.process(b, ws) == 0
+    ctx.synchronize()
+    ref_labels = ws["labels"].cpu().numpy().copy()
+    ctx.set_profiling(True, stages=[capi.MOD_STAGE_SCENE_FLOW, capi.MOD_STAGE_FINAL])
+    ctx.reset_stage_times()
+    for _ in range(3):
+        assert ctx.process(b, ws) == 0
+    times = [ctx.stage_time(i) for i in range(capi.MOD_STAGE_COUNT)]
+    for i, (ms, calls) in enumerate(times):
+        if i in (capi.MOD_STAGE_SCENE_FLOW, capi.MOD_STAGE_FINAL):
+            assert calls == 3 and ms > 0.0
+        else:
+            assert calls == 0 and ms == 0.0
+    ctx.set_profiling(True)
+    ctx.reset_stage_times()
+    assert ctx.process(b, ws) == 0
+    assert all(ctx.stage_time(i)[1] == 1 for i in range(capi.MOD_STAGE_COUNT))
+    ctx.set_profiling(False)
+    assert ctx.lib.mod_set_profiling(ctx.h, 0x80) == capi.MOD_ERR_INVALID_ARGUMENT      # not a stage bit
+    assert np.array_equal(ws["labels"].cpu().numpy(), ref_labels)
+    ctx.close()
