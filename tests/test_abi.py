@@ -69,3 +69,34 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "LIB_PATH", str(tmp_path / "libmod_sf.so"))
     with pytest.raises(ImportError):
         capi.load()
+
+
+def test_product_does_not_reach_the_oracle():
+    """The oracle is test infrastructure: nothing in the package imports it, the library does not link it, and bench.py
+    touches it only inside its cpu_baseline leg."""
+    import ast
+    import re
+    import subprocess
+    pkg = os.path.join(ROOT, "moving_object_detector_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                tree = ast.parse(open(os.path.join(dirpath, fn)).read())
+                for node in ast.walk(tree):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or ""]
+                    assert not any(n.split(".")[0] == "oracle" for n in names), (fn, names)
+            if fn.endswith((".hip", ".h", ".hpp", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r'#include\s+["<][^">]*oracle', src), fn
+    from moving_object_detector_amd import capi
+    needed = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liboracle" not in needed and "lookup_ref" not in needed
+    bench = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in ast.walk(bench):
+        if isinstance(fn, ast.FunctionDef):
+            uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in ast.walk(fn))
+            assert not uses or fn.name == "cpu_baseline", fn.name
