@@ -161,8 +161,29 @@ int main(int argc, char **argv) {
   run("V0 64x4, 4 px/thread (product)", [&] { hipLaunchKernelGGL((k_v0<false, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
   run("V0 + XCD remap", [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
   run("V0 + XCD remap + nontemporal stores", [&] { hipLaunchKernelGGL((k_v0<true, true>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
+  {   // placement: nine separate allocations vs one contiguous block vs 2 MiB-aligned, 2 MiB-padded planes
+    const size_t MB2 = (size_t)2 << 20;
+    for (int rep = 0; rep < 3; rep++) {
+      {
+        Args b = a; float *base[9];
+        for (int k = 0; k < 9; k++) CK(hipMalloc(&base[k], FN * (k == 2 ? 8 : 4)));
+        b.dn = base[0]; b.dp = base[1]; b.fl = base[2]; for (int k = 0; k < 6; k++) b.o[k] = base[3 + k];
+        char name[96]; snprintf(name, sizeof name, "separate allocations (base0 %% 2MiB = %zu KiB)", ((size_t)base[0] % MB2) >> 10);
+        run(name, [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+        for (int k = 0; k < 9; k++) CK(hipFree(base[k]));
+      }
+      {
+        Args b = a; char *blk; CK(hipMalloc(&blk, FN * 40 + 16 * MB2));
+        char *p = (char *)(((size_t)blk + MB2 - 1) / MB2 * MB2);
+        auto take = [&](size_t bytes) { char *r = p; p += (bytes + MB2 - 1) / MB2 * MB2; return (float *)r; };
+        b.dn = take(FN * 4); b.dp = take(FN * 4); b.fl = take(FN * 8); for (int k = 0; k < 6; k++) b.o[k] = take(FN * 4);
+        run("one block, planes 2 MiB aligned", [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+        CK(hipFree(blk));
+      }
+    }
+  }
   {   // same kernel, plane bases skewed against each other (do the 9 streams collide in the channel / bank hash?)
-    for (size_t skew : {(size_t)256, (size_t)4096 + 256, (size_t)65536 + 4096 + 256, (size_t)(1 << 20) + 65536 + 4096}) {
+    for (size_t skew : {(size_t)0, (size_t)4096, (size_t)65536 + 4096 + 256, (size_t)0}) {
       Args b = a;
       float *base[9];
       for (int k = 0; k < 9; k++) CK(hipMalloc(&base[k], FN * (k == 2 ? 8 : 4) + 16 * skew));
