@@ -515,34 +515,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   if (tid == 0) { hdr[0] = 1; hdr[1] = s_nreq; }   // s_nreq is final: the barrier after the request loop has passed
 }
 
-// Cross-tile links.  One WAVE per tile (most tiles have no dynamic pixel and no request: a workgroup each would spend the
-// kernel on workgroup dispatch), kLinkTilesPerWave tiles per wave so that their headers are fetched together.  The wave
-// walks a tile's requests (halo pixel h, tile root r): h's own tile has published parent[h] = its tile root by now, so the
-// union is between two tile roots — all parent writes here are atomicMin hooks on root entries.  Consecutive requests
-// usually name the same pair; only the first lane of a run acts.
-constexpr int kLinkTilesPerWave = 1, kMergeTilesPerWave = 4;
+// Cross-tile links.  One workgroup per kLinkTiles consecutive tiles (most tiles have no dynamic pixel and no request: a
+// workgroup each would spend the kernel on dispatch).  The tiles' request lists are walked as ONE index space by all 256
+// threads — every request is a chain of dependent global accesses (request, parent of the halo pixel, two root searches, a
+// hook), so what matters is how many are in flight, not which wave owns which tile.  A request is (halo pixel h, tile root r):
+// h's own tile has published parent[h] = its tile root by now, so the union is between two tile roots — all parent writes
+// here are atomicMin hooks on root entries.  Consecutive requests usually name the same pair; only the first lane of a run acts.
+constexpr int kLinkTiles = 8, kMergeTilesPerWave = 4;
 
 __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_per_frame) {
-  const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int t0 = (blockIdx.x * 4 + wv) * kLinkTilesPerWave;
-  int h0 = 0, h1 = 0;
-  if (lane < kLinkTilesPerWave && t0 + lane < tiles_per_frame) {
-    const int *hdr = a.tilehdr + ((size_t)f * tiles_per_frame + t0 + lane) * 2;
-    h0 = hdr[0]; h1 = hdr[1];
+  const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  const int t0 = blockIdx.x * kLinkTiles;
+  int cnt[kLinkTiles], total = 0;
+#pragma unroll
+  for (int u = 0; u < kLinkTiles; u++) {               // block-uniform scalar loads of the headers
+    cnt[u] = 0;
+    if (t0 + u < tiles_per_frame) {
+      const int *hdr = a.tilehdr + ((size_t)f * tiles_per_frame + t0 + u) * 2;
+      cnt[u] = hdr[0] ? hdr[1] : 0;
+    }
+    total += cnt[u];
   }
+  if (total == 0) return;
   const size_t N = (size_t)c.W * c.H;
   int *parent = a.parent + (size_t)f * N;
-  for (int u = 0; u < kLinkTilesPerWave; u++) {
-    const int nreq = __shfl(h0, u) ? __shfl(h1, u) : 0;
-    if (nreq == 0) continue;                           // wave-uniform
-    const uint2 *req = a.requests + ((size_t)f * tiles_per_frame + t0 + u) * a.req_cap;
-    for (int i0 = 0; i0 < nreq; i0 += 64) {
-      const int i = i0 + lane;
-      int ra = -1, rb = -1;
-      if (i < nreq) { const uint2 q = req[i]; ra = parent[q.x]; rb = (int)q.y; }
-      const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
-      if (ra >= 0 && !(lane > 0 && pa == ra && pb == rb)) uf_unite(parent, ra, rb);
+  for (int i0 = 0; i0 < total; i0 += 256) {            // block-uniform
+    int i = i0 + tid, u = 0;
+#pragma unroll
+    for (int v = 0; v < kLinkTiles - 1; v++) if (u == v && i >= cnt[v]) { i -= cnt[v]; u = v + 1; }
+    int ra = -1, rb = -1;
+    if (i0 + tid < total) {
+      const uint2 q = a.requests[((size_t)f * tiles_per_frame + t0 + u) * a.req_cap + i];
+      ra = parent[q.x]; rb = (int)q.y;
     }
+    const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
+    if (ra >= 0 && !(lane > 0 && pa == ra && pb == rb)) uf_unite(parent, ra, rb);
   }
 }
 
@@ -1383,7 +1390,7 @@ void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
 }
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 g = tile_grid(c, frames);
-  const int tiles = (int)(g.x * g.y), per_block = 4 * kLinkTilesPerWave;
+  const int tiles = (int)(g.x * g.y), per_block = kLinkTiles;
   hipLaunchKernelGGL(k_ccl_link, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles);
 }
 void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
