@@ -521,7 +521,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // hook), so what matters is how many are in flight, not which wave owns which tile.  A request is (halo pixel h, tile root r):
 // h's own tile has published parent[h] = its tile root by now, so the union is between two tile roots — all parent writes
 // here are atomicMin hooks on root entries.  Consecutive requests usually name the same pair; only the first lane of a run acts.
-constexpr int kLinkTiles = 8, kMergeTilesPerWave = 4;
+constexpr int kLinkTiles = 8;
 
 __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_per_frame) {
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -553,47 +553,40 @@ __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_
   }
 }
 
-// Root-level flatten, one wave per tile like k_ccl_link: every tile root finds its final root, remembers it (path
-// compression, so pixels are two hops from their final root), and folds its partial record into the final root's record;
-// final roots list themselves for k_select.
+// Root-level flatten: every tile root finds its final root, remembers it (path compression, so pixels are two hops from
+// their final root), and folds its partial record into the final root's record; final roots list themselves for k_select.
+// A wave takes 64 / TH tiles at once: lane = (tile, row of the tile) reads that row's root bits and walks them — the few roots
+// of a row one after the other, all rows and tiles of the wave side by side (each root is a chain of dependent accesses).
 template <int TH>
 __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles_per_frame) {
-  static_assert(TH <= 64, "one lane per tile row");
+  static_assert(64 % TH == 0, "a wave covers whole tiles");
+  constexpr int TPW = 64 / TH;                         // tiles per wave
   const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int t0 = (blockIdx.x * 4 + wv) * kMergeTilesPerWave;
-  int h0 = 0;
-  if (lane < kMergeTilesPerWave && t0 + lane < tiles_per_frame) h0 = a.tilehdr[((size_t)f * tiles_per_frame + t0 + lane) * 2];
+  const int t = (blockIdx.x * 4 + wv) * TPW + lane / TH, j = lane % TH;
   const size_t N = (size_t)c.W * c.H;
   int *parent = a.parent + (size_t)f * N;
   CompRec *recs = a.comps + (size_t)f * N;
-  for (int u = 0; u < kMergeTilesPerWave; u++) {
-    if (!__shfl(h0, u)) continue;                      // wave-uniform: nothing dynamic in the tile
-    const int t = t0 + u, wi = t % c.mask_words, ty = t / c.mask_words;
-    // lane j holds the root bits of the tile's row j
-    const int yrow = ty * TH + lane;
-    unsigned long long mine = 0ull;
-    if (lane < TH && yrow < c.H) mine = a.lroot[((size_t)f * c.H + yrow) * c.mask_words + wi];
-    unsigned long long rows = __ballot(mine != 0ull);
-    while (rows) {                                     // wave-uniform
-      const int j = __ffsll(rows) - 1;
-      rows &= rows - 1ull;
-      const unsigned long long rb = __shfl(mine, j);
-      if (!((rb >> lane) & 1ull)) continue;
-      const int p = (ty * TH + j) * c.W + wi * 64 + lane;
-      const int r = uf_find(parent, p);
-      if (r == p) {
-        const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
-        a.rootlist[(size_t)f * N + slot] = p;
-      } else {
-        parent[p] = r;   // r is final: no union runs after k_ccl_link
-        const CompRec rec = recs[p];
-        CompRec *t2 = recs + r;
-        atomicAdd(&t2->size, rec.size);
-        if (rec.key != kKeyNone) atomicMin(&t2->key, rec.key);
-        atomicMin(&t2->mn[0], rec.mn[0]); atomicMax(&t2->mx[0], rec.mx[0]);
-        atomicMin(&t2->mn[1], rec.mn[1]); atomicMax(&t2->mx[1], rec.mx[1]);
-        atomicMin(&t2->mn[2], rec.mn[2]); atomicMax(&t2->mx[2], rec.mx[2]);
-      }
+  if (t >= tiles_per_frame || a.tilehdr[((size_t)f * tiles_per_frame + t) * 2] == 0) return;   // nothing dynamic in the tile
+  const int wi = t % c.mask_words, ty = t / c.mask_words, y = ty * TH + j;
+  if (y >= c.H) return;
+  unsigned long long bits = a.lroot[((size_t)f * c.H + y) * c.mask_words + wi];
+  while (bits) {
+    const int b = __ffsll(bits) - 1;
+    bits &= bits - 1ull;
+    const int p = y * c.W + wi * 64 + b;
+    const int r = uf_find(parent, p);
+    if (r == p) {
+      const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
+      a.rootlist[(size_t)f * N + slot] = p;
+    } else {
+      parent[p] = r;   // r is final: no union runs after k_ccl_link
+      const CompRec rec = recs[p];
+      CompRec *t2 = recs + r;
+      atomicAdd(&t2->size, rec.size);
+      if (rec.key != kKeyNone) atomicMin(&t2->key, rec.key);
+      atomicMin(&t2->mn[0], rec.mn[0]); atomicMax(&t2->mx[0], rec.mx[0]);
+      atomicMin(&t2->mn[1], rec.mn[1]); atomicMax(&t2->mx[1], rec.mx[1]);
+      atomicMin(&t2->mn[2], rec.mn[2]); atomicMax(&t2->mx[2], rec.mx[2]);
     }
   }
 }
@@ -1395,7 +1388,7 @@ void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
 }
 void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 g = tile_grid(c, frames);
-  const int tiles = (int)(g.x * g.y), per_block = 4 * kMergeTilesPerWave;
+  const int tiles = (int)(g.x * g.y), per_block = 4 * (64 / kTileH);
   hipLaunchKernelGGL(k_ccl_merge<kTileH>, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles);
 }
 void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
