@@ -1,6 +1,7 @@
 // Memory skeletons of the scene-flow kernel's traffic (16 B/px read from 3 planes, 24 B/px written to 6 planes, one gather):
 // which thread / block shape streams it fastest on gfx950?  Build + run: see tools/membench/run.sh
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -79,6 +80,16 @@ __global__ __launch_bounds__(256) void k_rowil(Args a) {
   const uint32_t row = ((uint32_t)y * 6u * (uint32_t)a.W + (uint32_t)x0) * 4u;
 #pragma unroll
   for (int k = 0; k < 6; k++) st(base, row + (uint32_t)k * (uint32_t)a.W * 4u, q);
+}
+
+// one plane written (float4 per thread, the product's block shape): per-plane write bandwidth
+__global__ __launch_bounds__(256) void k_write1(float *o, int W, int H) {
+  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  remap(bx, by, bz, true);
+  const int x0 = (bx * 64 + threadIdx.x) * 4, y = by * 4 + threadIdx.y;
+  if (x0 >= W || y >= H) return;
+  const size_t fN = (size_t)bz * W * H;
+  st(o + fN, (uint32_t)(y * W + x0) * 4u, make_float4((float)x0, (float)y, 1.f, 2.f));
 }
 
 // V1: thread = 8 px (two float4 per plane), block 64x4 -> a wave covers 512 px of a row
@@ -161,6 +172,103 @@ int main(int argc, char **argv) {
   run("V0 64x4, 4 px/thread (product)", [&] { hipLaunchKernelGGL((k_v0<false, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
   run("V0 + XCD remap", [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
   run("V0 + XCD remap + nontemporal stores", [&] { hipLaunchKernelGGL((k_v0<true, true>), dim3(5, 180, F), dim3(64, 4), 0, 0, a); });
+  if (getenv("SPACING")) {   // one allocation, the nine planes laid out with a chosen gap between them: does the spacing set the speed?
+    const size_t KB = 1024, MBy = 1024 * 1024;
+    const size_t gaps[] = {0, 2 * MBy, 4 * MBy, 6 * MBy, 8 * MBy, 16 * MBy, 32 * MBy, 62 * MBy, 64 * KB, 256 * KB, 1 * MBy, 3 * MBy, 5 * MBy, 7 * MBy, 0, 2 * MBy};
+    char *blk; CK(hipMalloc(&blk, FN * 40 + 10 * 64 * MBy + 4 * MBy));
+    CK(hipMemset(blk, 0, FN * 40 + 10 * 64 * MBy + 4 * MBy));
+    char *blk0 = (char *)(((size_t)blk + 2 * MBy - 1) / (2 * MBy) * (2 * MBy));
+    for (size_t gap : gaps) {
+      Args b = a; char *p = blk0;
+      auto take = [&](size_t bytes) { char *r = p; p += bytes + gap; return (float *)r; };
+      b.dn = take(FN * 4); b.dp = take(FN * 4); b.fl = take(FN * 8); for (int k = 0; k < 6; k++) b.o[k] = take(FN * 4);
+      char name[96]; snprintf(name, sizeof name, "one block, gap %zu KiB between planes", gap / KB);
+      run(name, [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+    }
+    CK(hipFree(blk));
+    return 0;
+  }
+  if (getenv("PLANE_SIZES")) {   // single planes allocated with different (padded) sizes: does the allocation size decide the plane's write speed?
+    const size_t MBy = 1024 * 1024;
+    const size_t sizes[] = {FN * 4, FN * 4 + 2 * MBy, 512 * MBy, 1024 * MBy, 2048 * MBy};
+    std::vector<float *> keep;
+    for (size_t sz : sizes) {
+      printf("  planes of %4zu MiB allocations, written alone (GB/s):", sz / MBy);
+      for (int k = 0; k < 10; k++) {
+        float *o; CK(hipMalloc(&o, sz)); keep.push_back(o);
+        for (int i = 0; i < 2; i++) hipLaunchKernelGGL(k_write1, dim3(5, 180, F), dim3(64, 4), 0, 0, o, W, H);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < 10; i++) hipLaunchKernelGGL(k_write1, dim3(5, 180, F), dim3(64, 4), 0, 0, o, W, H);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+        printf(" %5.0f", 4.0 * FN / ms / 1e6);
+      }
+      printf("\n");
+    }
+    for (float *q : keep) CK(hipFree(q));
+    return 0;
+  }
+  if (getenv("BLOCK_TRIALS")) {   // like PLACEMENT_TRIALS, but every set of nine planes is carved out of ONE allocation
+    const int trials = atoi(getenv("BLOCK_TRIALS"));
+    const size_t MB2 = (size_t)2 << 20;
+    std::vector<char *> keep;
+    for (int tr = 0; tr < trials; tr++) {
+      Args b = a; char *blk; CK(hipMalloc(&blk, FN * 40 + 16 * MB2)); keep.push_back(blk);
+      CK(hipMemset(blk, 0, FN * 40 + 16 * MB2));
+      char *p = (char *)(((size_t)blk + MB2 - 1) / MB2 * MB2);
+      auto take = [&](size_t bytes) { char *r = p; p += (bytes + MB2 - 1) / MB2 * MB2; return (float *)r; };
+      b.dn = take(FN * 4); b.dp = take(FN * 4); b.fl = take(FN * 8); for (int k = 0; k < 6; k++) b.o[k] = take(FN * 4);
+      char name[96]; snprintf(name, sizeof name, "block trial %d (va %p)", tr, (void *)blk);
+      run(name, [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+    }
+    for (char *q : keep) CK(hipFree(q));
+    return 0;
+  }
+  if (getenv("PLACEMENT_TRIALS")) {   // same kernel on fresh sets of nine planes, earlier sets kept alive: how much does placement matter?
+    const int trials = atoi(getenv("PLACEMENT_TRIALS"));
+    std::vector<float *> keep;
+    for (int tr = 0; tr < trials; tr++) {
+      Args b = a; float *base[9];
+      for (int k = 0; k < 9; k++) { CK(hipMalloc(&base[k], FN * (k == 2 ? 8 : 4))); keep.push_back(base[k]); }
+      b.dn = base[0]; b.dp = base[1]; b.fl = base[2]; for (int k = 0; k < 6; k++) b.o[k] = base[3 + k];
+      CK(hipMemset(base[0], 0, FN * 4)); CK(hipMemset(base[1], 0, FN * 4)); CK(hipMemset(base[2], 0, FN * 8));
+      char name[96]; snprintf(name, sizeof name, "placement trial %d (va %p)", tr, (void *)base[0]);
+      run(name, [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+    }
+    for (int round = 0; round < 1; round++)            // the same sets again: is the speed a property of the set or of the moment?
+      for (int tr = 0; tr < trials; tr++) {
+        Args b = a; float **base = &keep[9 * tr];
+        b.dn = base[0]; b.dp = base[1]; b.fl = base[2]; for (int k = 0; k < 6; k++) b.o[k] = base[3 + k];
+        char name[96]; snprintf(name, sizeof name, "  again: set %d", tr);
+        run(name, [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+      }
+    {   // every output plane of every set written alone
+      for (int tr = 0; tr < trials; tr++) {
+        printf("  set %d, planes written alone (GB/s):", tr);
+        for (int k = 3; k < 9; k++) {
+          float *o = keep[9 * tr + k];
+          for (int i = 0; i < 2; i++) hipLaunchKernelGGL(k_write1, dim3(5, 180, F), dim3(64, 4), 0, 0, o, W, H);
+          CK(hipEventRecord(e0));
+          for (int i = 0; i < 10; i++) hipLaunchKernelGGL(k_write1, dim3(5, 180, F), dim3(64, 4), 0, 0, o, W, H);
+          CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+          printf(" %5.0f", 4.0 * FN / ms / 1e6);
+        }
+        printf("\n");
+      }
+    }
+    {   // inputs of one set with outputs of another: which side carries the effect?
+      for (int i = 0; i < std::min(trials, 4); i++)
+        for (int j = 0; j < std::min(trials, 4); j++) {
+          Args b = a; float **bi = &keep[9 * i], **bo = &keep[9 * j];
+          b.dn = bi[0]; b.dp = bi[1]; b.fl = bi[2]; for (int k = 0; k < 6; k++) b.o[k] = bo[3 + k];
+          char name[96]; snprintf(name, sizeof name, "  inputs of set %d, outputs of set %d", i, j);
+          run(name, [&] { hipLaunchKernelGGL((k_v0<true, false>), dim3(5, 180, F), dim3(64, 4), 0, 0, b); });
+        }
+    }
+    for (float *q : keep) CK(hipFree(q));
+    return 0;
+  }
   {   // placement: nine separate allocations vs one contiguous block vs 2 MiB-aligned, 2 MiB-padded planes
     const size_t MB2 = (size_t)2 << 20;
     for (int rep = 0; rep < 3; rep++) {
