@@ -172,7 +172,7 @@ __device__ __forceinline__ void wave_unite_lds(int *L, bool need, int &cur, int 
 //   C  publish: interior pixels hook onto their tile root, linked halo pixels are united with it in HBM (atomicMin
 //      only), tile roots get an empty statistics record
 //   D  partial statistics (size, first_edge_key, bbox) of the tile's components, one set of atomics per (wave, root)
-template <int TH, int NMAX, int NW>
+template <int TH, int NMAX, int NW, bool EXACT>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ccl_tile(DevCam c, ClArgs a) {
   constexpr int RPW = TH / NW;                      // rows per wave (NW waves per tile)
   constexpr int PW = 64 + NMAX, PH = TH + NMAX, G = PW * PH;
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // index derived from it stays on the scalar unit
   const int lane = threadIdx.x, w = __builtin_amdgcn_readfirstlane((int)threadIdx.y), tid = w * 64 + lane;
   const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
-  const int MW = c.mask_words, n = c.n;
+  // EXACT: neighbor_distance equals the instance's halo width (the default n = 4 does): the window loops get constant bounds
+  const int MW = c.mask_words, n = EXACT ? NMAX : c.n;
   const size_t N = (size_t)c.W * c.H;
   const size_t fN = (size_t)f * N;
   if (tid == 0) { s_any = 0; s_nreq = 0; s_nslots = 0; }
@@ -1377,9 +1378,10 @@ static dim3 tile_grid(const DevCam &c, int frames) { return dim3(c.mask_words, (
 
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 block(64, kTileWaves, 1), tgrid = tile_grid(c, frames);
-  if (c.n <= 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves>), tgrid, block, 0, s, c, a);
-  else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves>), tgrid, block, 0, s, c, a);
-  else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16, kTileWaves>), tgrid, block, 0, s, c, a);
+  if (c.n == 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, true>), tgrid, block, 0, s, c, a);
+  else if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, false>), tgrid, block, 0, s, c, a);
+  else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves, false>), tgrid, block, 0, s, c, a);
+  else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16, kTileWaves, false>), tgrid, block, 0, s, c, a);
 }
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 g = tile_grid(c, frames);
