@@ -326,7 +326,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     int cur = dyn ? ld_relaxed(&Lt[me]) : -1, last = -1;
     bool up = upr[j];
     COUNT(13, 1)
-    for (int dv = 0; dv <= n; dv++) {
+#pragma unroll
+    for (int dv = 0; dv <= (EXACT ? NMAX : n); dv++) {   // unrolled in the EXACT instance
       const int qg = rr + NMAX - dv;                 // grid row of the window row
       const uint64_t q0 = m0[qg], qL = mL[qg];
       if ((q0 | qL) == 0) continue;                  // wave-uniform
