@@ -179,7 +179,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __shared__ float zt[G];
   __shared__ int Lt[G];
   __shared__ uint64_t m0[PH], mL[PH];
-  __shared__ int rowlab[PH];                        // common label of a row's dynamic interior pixels, -1 if they differ
   constexpr int kSlots = 32;
   __shared__ int s_any, s_nreq, s_nslots;
   __shared__ CompRec srec[kSlots];
@@ -296,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     upr[j] = upr[j] || link;
   }
   lds_barrier();
-  // ---- phase A3: flatten, so that phase B can compare labels directly; note rows whose dynamic pixels share one label --
+  // ---- phase A3: flatten, so that phase B can compare labels directly -------------------------------------------------
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
@@ -304,13 +303,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const bool dyn = (mw >> lane) & 1ull;
     int lab = -1;
     if (dyn) { lab = lds_find(Lt, me); if (lab != me) Lt[me] = lab; }
-    if (mw) {                                        // wave-uniform
-      const int first = __shfl(lab, __ffsll((unsigned long long)mw) - 1);
-      const bool same = __ballot(dyn && lab != first) == 0;
-      if (lane == 0) rowlab[rr + NMAX] = same ? first : -1;
-    } else if (lane == 0) rowlab[rr + NMAX] = -1;
   }
-  if (tid < NMAX) rowlab[tid] = -1;                  // halo rows: every cell is its own node
   lds_barrier();
   STAMP(1)
   // ---- phase B: the rest of the up-left window --------------------------------------------------------------------------
@@ -331,10 +324,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       const int qg = rr + NMAX - dv;                 // grid row of the window row
       const uint64_t q0 = m0[qg], qL = mL[qg];
       if ((q0 | qL) == 0) continue;                  // wave-uniform
-      // Window row and own row carry one common label and nothing dynamic sits in the left halo: no union can come out
-      // of this row; it is only needed by lanes that still look for their first up-left edge.
-      const int rl = rowlab[qg];
-      if (rl >= 0 && rl == rowlab[rr + NMAX] && (qL >> (64 - n)) == 0 && __ballot(dyn && !up) == 0) continue;
       // bit i of nb = pixel (lane - n + i) of the window row is dynamic  (i = n - k)
       uint32_t nb;
       if (lane >= n) nb = (uint32_t)(q0 >> (lane - n));
