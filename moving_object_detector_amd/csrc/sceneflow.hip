@@ -232,6 +232,10 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     sf_stage1(c, fc, x0 + 1, y, dn.y, dp.y, fa.z, fa.w, rxa.y, ry, p1, s1);
     sf_stage1(c, fc, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2, s2);
     sf_stage1(c, fc, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3, s3);
+    // x, y, z are final after stage 1: their stores leave before the gathers come back
+    st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
+    st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
+    st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
     // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets
     const uint32_t W = (uint32_t)c.W;
     const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
@@ -253,9 +257,6 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
       sf_stage2b(c, fc, s2, w2, p2);
       sf_stage2b(c, fc, s3, w3, p3);
     }
-    st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
-    st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
-    st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
     st(a.vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
     st(a.vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
     st(a.vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
@@ -306,6 +307,9 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
     PxState s0, s1;
     sf_stage1(c, fc, x0 + 0, y, dn.x, dp.x, fl.x, fl.y, rx.x, ry, p0, s0);
     sf_stage1(c, fc, x0 + 1, y, dn.y, dp.y, fl.z, fl.w, rx.y, ry, p1, s1);
+    st(a.x + fN, o4, make_float2(p0.x, p1.x));       // final after stage 1: out before the gathers come back
+    st(a.y + fN, o4, make_float2(p0.y, p1.y));
+    st(a.z + fN, o4, make_float2(p0.z, p1.z));
     const uint32_t W = (uint32_t)c.W;
     const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
     const float g1 = ld<float>(dprev_f, ((uint32_t)s1.py * W + (uint32_t)s1.px) * 4u);
@@ -318,9 +322,6 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
       sf_stage2b(c, fc, s0, w0, p0);
       sf_stage2b(c, fc, s1, w1, p1);
     }
-    st(a.x + fN, o4, make_float2(p0.x, p1.x));
-    st(a.y + fN, o4, make_float2(p0.y, p1.y));
-    st(a.z + fN, o4, make_float2(p0.z, p1.z));
     st(a.vx + fN, o4, make_float2(p0.vx, p1.vx));
     st(a.vy + fN, o4, make_float2(p0.vy, p1.vy));
     st(a.vz + fN, o4, make_float2(p0.vz, p1.vz));
