@@ -22,9 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import numpy as np
-import torch
+# numpy / torch are imported inside main(): with --gpus N > 1 this process only starts the N ranks and must not touch the GPU
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0
@@ -47,11 +45,17 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU (bounded sample)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--workload", default="sequence", choices=["sequence", "pairs"],
+                    help="sequence: one synthetic stream (frame t's now-disparity is frame t+1's previous), sharded over the ranks "
+                         "as contiguous chunks + a one-plane disparity halo (SURVEY.md 8(e)); pairs: round 1's independent pairs")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous + config broadcast + stream sharding only, no GPU work (exercises the N-rank launch path on a CPU box)")
     return ap.parse_args()
 
 
 def cpu_baseline(cam, prm, batch, n_sample):
     """Times the oracle on this box's host cores on the first n_sample pairs of rank 0's batch."""
+    import numpy as np  # noqa: F401
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import pyoracle
@@ -101,26 +105,40 @@ def cpu_baseline(cam, prm, batch, n_sample):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call (torch is not even imported),
+        # starts N fresh ranks exactly as the driver would (torch.distributed.run, one process per GPU) and relays their exit code.
+        from moving_object_detector_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU and pass the same N\n")
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+
+    import numpy as np
+    import torch
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group(args.backend)
 
     from moving_object_detector_amd import capi, synth
     from moving_object_detector_amd import dist as mdist
-    from moving_object_detector_amd.pipeline import PLANES, Context
+
+    if not args.launch_check:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        if args.share_device:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if not args.launch_check else torch.device("cpu")
+    on_dev = args.backend == "nccl" and not args.launch_check
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if on_dev:
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo" if args.launch_check else args.backend)
 
     W, H, F = args.width, args.height, args.frames
     G = max(1, min(args.distinct, F))
@@ -129,14 +147,36 @@ def main():
     if rank == 0:
         cam_s = capi.camera_struct(synth.make_camera(W, H, args.camera))
         prm_s = capi.params_struct(synth.Params())
-    cam_s, prm_s = mdist.broadcast_config(cam_s, prm_s, src=0, device=dev if args.backend == "nccl" else None)
+    cam_s, prm_s = mdist.broadcast_config(cam_s, prm_s, src=0, device=dev if on_dev else None)
 
-    # synthetic pairs of this rank's shard (distinct seeds per rank), tiled to F frames at distinct HBM addresses
-    cam, host = synth.make_batch(W, H, G, seed=0, first_frame=rank * G, camera=args.camera)
+    total = world * G                                   # distinct frames of the whole job's stream
+    lo, hi = mdist.shard_range(total, rank, world)
+    if args.launch_check:
+        counts = mdist.gather_counts(torch.tensor([lo, hi], dtype=torch.int32))
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": "gloo", "camera_width": cam_s.width,
+                              "cluster_size": prm_s.cluster_size, "shards": [c.tolist() for c in counts]}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    from moving_object_detector_amd.pipeline import PLANES, Context
+
+    # this rank's share of the stream, tiled to F frames at distinct HBM addresses
+    if args.workload == "sequence":
+        # one stream of `total` frames; a rank materialises its contiguous chunk + the one-plane disparity halo
+        mk = lambda first, frames: synth.make_sequence(W, H, frames, seed=0, first=first, camera=args.camera)[1]
+        sh = mdist.local_stream(mk, total, rank, world)
+        cam = synth.make_camera(W, H, args.camera)
+        host = {"disparity_now": sh["disparity_now"], "disparity_prev": sh["disparity_prev"], "flow": sh["flow"],
+                "t": sh["t"], "q": sh["q"], "dt": sh["dt"]}
+    else:
+        cam, host = synth.make_batch(W, H, G, seed=0, first_frame=rank * G, camera=args.camera)
     idx = [i % G for i in range(F)]
-    d_now = torch.from_numpy(host["disparity_now"]).to(dev)[idx].contiguous()
-    d_prev = torch.from_numpy(host["disparity_prev"]).to(dev)[idx].contiguous()
-    flow = torch.from_numpy(host["flow"]).to(dev)[idx].contiguous()
+    d_now = torch.from_numpy(np.ascontiguousarray(host["disparity_now"])).to(dev)[idx].contiguous()
+    d_prev = torch.from_numpy(np.ascontiguousarray(host["disparity_prev"])).to(dev)[idx].contiguous()
+    flow = torch.from_numpy(np.ascontiguousarray(host["flow"])).to(dev)[idx].contiguous()
     ts, qs, dts = host["t"][idx], host["q"][idx], host["dt"][idx]
 
     ctx = Context(W, H, max_frames=F, device=local_rank)
@@ -217,7 +257,7 @@ def main():
             },
         }
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:                     # rank 0 only, also when N > 1 (the other ranks wait at the last barrier)
             prm = synth.Params()
             cpu, refs = cpu_baseline(cam, prm, host, args.cpu_sample)
             # same-run output check of the sampled pairs against the oracle
@@ -239,13 +279,17 @@ def main():
             "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic sequence ({args.camera}-style camera), scene-flow + cluster kernels only (disparity/flow precomputed, "
                                    f"HBM-resident), reference default parameters",
-                       "frames_per_step_per_gpu": F, "distinct_frames_per_gpu": G, "sharding": f"frames x{world}",
+                       "frames_per_step_per_gpu": F, "distinct_frames_per_gpu": G,
+                       "stream": ("one synthetic stream, contiguous chunk per rank + one disparity plane of halo" if args.workload == "sequence"
+                                  else "independent synthetic pairs per rank"),
+                       "sharding": f"frames x{world}",
                        "collective": "one RCCL broadcast of the intrinsics/params block before the timed region"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -48,6 +48,34 @@ def shard_range(total_frames: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_stream(disparity, flow, t, q, dt, rank: int, world: int):
+    """Rank `rank`'s share of a stream: a contiguous chunk of frames plus ONE disparity plane of halo.
+
+    A stream of F frames is `disparity` [F+1] planes (frame i pairs previous = disparity[i] with now = disparity[i+1], the
+    reference's `disparity_previous_ = disparity_now_`, scene_flow_constructor.cpp:397-398) and per-frame `flow`, `t`, `q`, `dt`
+    [F].  The chunk [lo, hi) of shard_range needs planes lo .. hi: its first frame's "previous" plane is the halo — the plane
+    the rank before it produced last.  Works on anything sliceable along axis 0 (numpy arrays, torch tensors); returns views:
+    {"lo", "hi", "disparity" [hi-lo+1], "disparity_prev" [hi-lo] (= disparity[:-1]), "disparity_now" [hi-lo] (= disparity[1:]),
+     "flow", "t", "q", "dt" [hi-lo]}.
+    """
+    F = len(flow)
+    if len(disparity) != F + 1 or len(t) != F or len(q) != F or len(dt) != F:
+        raise ValueError("a stream of F frames has F+1 disparity planes and F flows / transforms / dts")
+    lo, hi = shard_range(F, rank, world)
+    d = disparity[lo:hi + 1]
+    return {"lo": lo, "hi": hi, "disparity": d, "disparity_prev": d[:hi - lo], "disparity_now": d[1:hi - lo + 1],
+            "flow": flow[lo:hi], "t": t[lo:hi], "q": q[lo:hi], "dt": dt[lo:hi]}
+
+
+def local_stream(make, total_frames: int, rank: int, world: int):
+    """shard_stream for a stream that is a deterministic function of its frame index: `make(first, frames)` returns
+    {"disparity" [frames+1], "flow", "t", "q", "dt" [frames]} for stream frames first .. first+frames-1 (e.g.
+    synth.make_sequence), so each rank materialises only its chunk + the one-plane halo.  Same dict as shard_stream."""
+    lo, hi = shard_range(total_frames, rank, world)
+    s = make(lo, hi - lo)
+    return shard_stream(s["disparity"], s["flow"], s["t"], s["q"], s["dt"], 0, 1) | {"lo": lo, "hi": hi}
+
+
 def gather_counts(local_counts: torch.Tensor):
     """Optional ordered view for rank 0: all-gather of per-frame object counts (equal shard sizes)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -254,3 +254,159 @@ def make_batch(width: int, height: int, frames: int, seed: int = 0, first_frame:
         _, fr = make_frame(width, height, seed, first_frame + i, **kw)
         dn[i], dp[i], fl[i], ts[i], qs[i], dts[i] = fr.disparity_now, fr.disparity_prev, fr.flow, fr.translation, fr.quaternion, fr.dt
     return cam, {"disparity_now": dn, "disparity_prev": dp, "flow": fl, "t": ts, "q": qs, "dt": dts}
+
+
+# ---- a proper stream: frame t's "now" disparity IS frame t+1's "previous" disparity --------------------------------------
+def _ego_step(seed: int, k: int):
+    """previous(k-1) -> now(k) camera motion of stream frame k, seeded per frame index (so any sub-range of the stream can be
+    generated on its own, e.g. one rank's shard)."""
+    rng = np.random.Generator(np.random.PCG64([0x5EED1000 + seed, k, 1]))
+    t = np.array([0.01, 0.0, 0.08]) * (1.0 + 0.2 * rng.uniform(-1, 1, 3))
+    yaw = np.deg2rad(0.4) * (1.0 + 0.2 * rng.uniform(-1, 1)) * (1.0 if (k // 32) % 2 == 0 else -1.0)   # weave, do not circle
+    pitch = np.deg2rad(0.1) * rng.uniform(-1, 1)
+    q = _quat_from_yaw_pitch(yaw, pitch)
+    return t, q, _rot(q)
+
+
+def _tri(k: float, period: int) -> float:
+    """Triangle wave in [-1, 1] with the given period (object paths go back and forth and stay in view)."""
+    u = (k / period) % 1.0
+    return 4.0 * u - 1.0 if u < 0.5 else 3.0 - 4.0 * u
+
+
+class _Scene:
+    """World of one stream: wall + ground + moving boxes, all a function of (seed, size) only.  World = camera frame 0."""
+
+    def __init__(self, cam: Camera, seed: int, n_objects: int, n_small: int):
+        self.cam = cam
+        W, H = cam.width, cam.height
+        rng = np.random.Generator(np.random.PCG64([0x5EED1000 + seed, 0, 2]))
+        self.wall_z, self.cam_h = 60.0 + 10.0 * rng.uniform(), 1.5
+        sc = W / 1280.0
+        self.boxes = []
+        for k in range(n_objects + n_small):
+            small = k >= n_objects
+            if small:
+                bw, bh = int(rng.integers(24, 44) * sc), int(rng.integers(24, 44) * sc)
+            else:
+                bw, bh = int(rng.integers(90, 261) * sc), int(rng.integers(120, 401) * sc)
+            bw, bh = max(bw, 3), max(bh, 3)
+            zc = rng.uniform(4.0, 9.0)
+            x0 = int(rng.integers(8, max(9, W - bw - 8)))
+            y0 = int(rng.integers(8, max(9, H - bh - 8)))
+            speed = rng.uniform(1.0, 2.0)
+            ang = rng.uniform(0, 2 * np.pi)
+            v = np.array([speed * np.cos(ang), 0.15 * speed * rng.uniform(-1, 1), 0.5 * speed * np.sin(ang)])
+            slant = rng.uniform(-0.3, 0.3)                 # depth change across the box [m]
+            # metric size and centre RELATIVE TO THE CAMERA (the boxes ride along with the vehicle, like traffic ahead of it)
+            wm, hm = bw * zc / cam.fx, bh * zc / cam.fy
+            c0 = np.array([(x0 + bw / 2.0 - cam.cx) / cam.fx * zc, (y0 + bh / 2.0 - cam.cy) / cam.fy * zc, zc])
+            period = int(rng.integers(6, 14))
+            self.boxes.append((c0, v, wm, hm, slant, period, float(rng.uniform(0, 1))))
+
+    def box_centre(self, j: int, k: int, dt: float) -> np.ndarray:
+        """Centre of box j in the camera frame of stream index k: a constant-speed back-and-forth path around c0, so the
+        camera-relative velocity between consecutive frames is +-v (1-2 m/s) — what the residual test sees."""
+        c0, v, _, _, _, period, ph = self.boxes[j]
+        return c0 + v * dt * (period / 4.0) * _tri(k + ph * period, period)
+
+
+def _render(scene: _Scene, A: np.ndarray, b: np.ndarray, k: int, dt: float, xs, ys):
+    """Depth and object id seen by the camera of stream index k (P_k = A P_world + b)."""
+    cam = scene.cam
+    H, W = xs.shape
+    z = _background_depth(cam, -A.T @ b, A.T, xs, ys, scene.wall_z, scene.cam_h)
+    obj = np.full((H, W), -1, np.int32)
+    cents = [scene.box_centre(j, k, dt) for j in range(len(scene.boxes))]
+    for j in np.argsort([-c[2] for c in cents]):           # far to near, near overwrites
+        c = cents[j]
+        _, _, wm, hm, slant, _, _ = scene.boxes[j]
+        pw, ph = wm * cam.fx / c[2], hm * cam.fy / c[2]
+        px0 = int(round(cam.fx * c[0] / c[2] + cam.cx - pw / 2.0))
+        py0 = int(round(cam.fy * c[1] / c[2] + cam.cy - ph / 2.0))
+        xa, xb = max(px0, 0), min(px0 + int(round(pw)), W)
+        ya, yb = max(py0, 0), min(py0 + int(round(ph)), H)
+        if xa >= xb or ya >= yb:
+            continue
+        sl = (slice(ya, yb), slice(xa, xb))
+        zz = c[2] + slant * (xs[sl] - (px0 + pw / 2.0)) / max(pw, 1.0)
+        closer = zz < z[sl]
+        z[sl] = np.where(closer, zz, z[sl])
+        obj[sl] = np.where(closer, j, obj[sl])
+    return z, obj
+
+
+def make_sequence(width: int, height: int, frames: int, seed: int = 0, first: int = 0, *, n_objects: int = 6, n_small: int = 2,
+                  n_isolated: int = 24, dt: float = 0.1, quantize: bool = True, invalid: bool = True, camera: str = "zed"):
+    """A stream as the reference's stereoCallback sees it (scene_flow_constructor.cpp:364-399): disparity planes D[first ..
+    first + frames] (frames + 1 planes: frame t pairs previous = D[t] with now = D[t + 1], as `disparity_previous_ =
+    disparity_now_` does, :397-398), and per frame t the flow at the now pixel, the previous->now transform and dt.
+
+    Every plane / frame is a function of (seed, its own stream index) only, so a rank can generate exactly its shard
+    (contiguous chunk + one disparity plane of halo) and get the bytes a single process would.
+    Returns (camera, {"disparity": (frames+1,H,W), "flow": (frames,H,W,2), "t": (frames,3), "q": (frames,4), "dt": (frames,)}).
+    """
+    cam = make_camera(width, height, camera)
+    W, H = width, height
+    scene = _Scene(cam, seed, n_objects, n_small)
+    f, base = float(cam.disp_f), float(cam.disp_T)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    # pose of camera index i (plane D[i]): P_i = A_i P_world + b_i, chained from index 0
+    A, b = np.eye(3), np.zeros(3)
+    for i in range(1, first + 1):
+        t_, _, R_ = _ego_step(seed, i)
+        A, b = R_ @ A, R_ @ b + t_
+
+    def plane(i, A, b):
+        z, obj = _render(scene, A, b, i, dt, xs, ys)
+        d = f * base / z
+        if quantize:
+            d = np.round(d * 4.0) / 4.0
+        d = d.astype(np.float32)
+        if invalid:
+            u = np.random.Generator(np.random.PCG64([0x5EED1000 + seed, i, 3])).random((H, W))
+            d[u < 0.03] = np.nan
+            d[(u >= 0.03) & (u < 0.04)] = -1.0
+            d[(u >= 0.04) & (u < 0.05)] = 0.0
+            d[(u >= 0.05) & (u < 0.06)] = 200.0
+        return d, z, obj
+
+    D = np.empty((frames + 1, H, W), np.float32)
+    fl = np.empty((frames, H, W, 2), np.float32)
+    ts = np.empty((frames, 3), np.float64)
+    qs = np.empty((frames, 4), np.float64)
+    dts = np.full((frames,), float(dt), np.float64)
+    D[0], _, _ = plane(first, A, b)
+    for n in range(frames):
+        i = first + n + 1                                  # stream index of the "now" plane of frame first + n
+        t_, q_, R_ = _ego_step(seed, i)
+        A, b = R_ @ A, R_ @ b + t_
+        D[n + 1], z_now, obj = plane(i, A, b)
+        # flow at the now pixel: where was this surface point one frame ago, in the previous camera?
+        Pn = np.stack([(xs - cam.cx) / cam.fx * z_now, (ys - cam.cy) / cam.fy * z_now, z_now], -1)
+        disp = np.zeros((H, W, 3))                         # camera-relative displacement of the surface since the last frame
+        for j in range(len(scene.boxes)):
+            disp[obj == j] = scene.box_centre(j, i, dt) - scene.box_centre(j, i - 1, dt)
+        # background: P_prev = R^T (P_now - t); a box rides with the camera: its point was at (P_now - disp) in the previous
+        # camera's own coordinates
+        Pp = np.where((obj >= 0)[..., None], Pn - disp, (Pn - t_) @ R_)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xp = cam.fx * Pp[..., 0] / Pp[..., 2] + cam.cx
+            yp = cam.fy * Pp[..., 1] / Pp[..., 2] + cam.cy
+        rng = np.random.Generator(np.random.PCG64([0x5EED1000 + seed, i, 4]))
+        flow = np.stack([xs - xp, ys - yp], -1) + rng.uniform(-0.3, 0.3, (H, W, 2))
+        flow = flow.astype(np.float32)
+        mg = min(40, W // 8, H // 8)
+        for _ in range(n_isolated):                        # isolated dynamic pixels: flow outliers on the background
+            x, y = int(rng.integers(mg, W - mg)), int(rng.integers(mg, H - mg))
+            a, r = rng.uniform(0, 2 * np.pi), rng.uniform(10, 30)
+            if obj[y, x] < 0:
+                flow[y, x, 0] += np.float32(r * np.cos(a))
+                flow[y, x, 1] += np.float32(r * np.sin(a))
+        if invalid:
+            u = rng.random((H, W))
+            flow[u < 0.01] = np.nan
+            huge = (u >= 0.01) & (u < 0.011)
+            flow[huge] = np.where(rng.random((int(huge.sum()), 2)) < 0.5, np.float32(-1e6), np.float32(1e6))
+        fl[n], ts[n], qs[n] = flow, t_, q_
+    return cam, {"disparity": D, "flow": fl, "t": ts, "q": qs, "dt": dts}

@@ -1,0 +1,85 @@
+"""CPU: `bench.py --gpus N` really starts N ranks (fresh children, torch.distributed.run) and a stream shards correctly."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_gpus_2_spawns_two_ranks():
+    r = _bench("--gpus", "2", "--launch-check", "--distinct", "5")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # ONE line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["shards"] == [[0, 5], [5, 10]] and j["camera_width"] == 1280 and j["cluster_size"] == 2500
+
+
+def test_gpus_world_size_mismatch_fails():
+    r = _bench("--gpus", "2", "--launch-check", env={"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_launcher_does_not_import_torch():
+    # the launcher process must not be able to touch the GPU: torch is not even imported before the ranks are started
+    code = ("import sys, runpy\n"
+            "import moving_object_detector_amd.launch as L\n"
+            "L.spawn_ranks = lambda *a, **k: (print('TORCH' if 'torch' in sys.modules else 'CLEAN'), 0)[1]\n"
+            "sys.argv = ['bench.py', '--gpus', '4']\n"
+            "runpy.run_path('bench.py', run_name='__main__')\n")
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=120)
+    assert "CLEAN" in r.stdout, (r.stdout, r.stderr[-1500:])
+
+
+def test_rank_command_is_the_drivers():
+    from moving_object_detector_amd.launch import rank_command
+    c = rank_command("bench.py", ["--gpus", "8"], 8, 29511)
+    assert c[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in c
+    assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-3:] == ["bench.py", "--gpus", "8"]
+
+
+def test_sequence_is_a_function_of_the_frame_index():
+    from moving_object_detector_amd import synth
+    _, full = synth.make_sequence(96, 64, 5, seed=4)
+    assert full["disparity"].shape == (6, 64, 96) and full["flow"].shape == (5, 64, 96, 2)
+    _, part = synth.make_sequence(96, 64, 2, seed=4, first=3)
+    assert part["disparity"].tobytes() == full["disparity"][3:6].tobytes()
+    assert part["flow"].tobytes() == full["flow"][3:5].tobytes()
+    assert part["t"].tobytes() == full["t"][3:5].tobytes() and part["q"].tobytes() == full["q"][3:5].tobytes()
+    d = full["disparity"]
+    assert np.isnan(d).any() and (d == 0).any() and (d < 0).any() and (d > 128).any() and np.isnan(full["flow"]).any()
+
+
+def test_shard_stream_chunks_plus_halo():
+    from moving_object_detector_amd import dist as mdist
+    from moving_object_detector_amd import synth
+    _, s = synth.make_sequence(64, 48, 7, seed=2)
+    mk = lambda first, frames: synth.make_sequence(64, 48, frames, seed=2, first=first)[1]
+    for world in (1, 2, 3, 8):
+        seen = []
+        for r in range(world):
+            a = mdist.shard_stream(s["disparity"], s["flow"], s["t"], s["q"], s["dt"], r, world)
+            b = mdist.local_stream(mk, 7, r, world)
+            n = a["hi"] - a["lo"]
+            assert (a["lo"], a["hi"]) == (b["lo"], b["hi"]) and len(a["disparity"]) == n + 1
+            for k in ("disparity", "disparity_prev", "disparity_now", "flow", "t", "q", "dt"):
+                assert np.asarray(a[k]).tobytes() == np.asarray(b[k]).tobytes(), (world, r, k)
+            # the halo: the first frame's previous plane is the plane before the chunk, i.e. the last "now" of the rank before
+            if n:
+                assert a["disparity_prev"][0].tobytes() == s["disparity"][a["lo"]].tobytes()
+                assert a["disparity_now"][-1].tobytes() == s["disparity"][a["hi"]].tobytes()
+            seen += list(range(a["lo"], a["hi"]))
+        assert seen == list(range(7))
