@@ -150,6 +150,14 @@ int  mod_synchronize(ModContext *ctx);                      /* wait for everythi
  * (scene_flow_constructor.cpp:91-147) as one fused kernel; also emits the dynamic mask when requested. */
 int  mod_scene_flow_dev(ModContext *ctx, const ModFrameBatch *in, const ModSceneFlowPlanes *out);
 
+/* ~depth alone: toDepthImage (disparity_image_proc/src/disparity_image_processor.cpp:105-120).  construct() publishes it whenever
+ * disparity_now exists — also on frames that end at one of its guards without scene flow (scene_flow_constructor.cpp:110-123).
+ * mod_scene_flow_dev / mod_process_dev follow that: when they return a skip code other than MOD_SKIP_NO_DISPARITY_NOW and
+ * out->depth was requested, the depth plane HAS been enqueued (all other outputs are untouched).  These two entry points
+ * give the depth image without a batch (device planes [frames][H][W]; host: one frame).  NULL disparity -> MOD_SKIP_NO_DISPARITY_NOW. */
+int  mod_depth_image_dev(ModContext *ctx, int32_t frames, const float *disparity_now, float *depth);
+int  mod_depth_image_host(ModContext *ctx, const float *disparity_now, float *depth);
+
 /* calculateDynamicMap (clusterer_nodelet.cpp:40-54) for a cloud that did not come from mod_scene_flow_dev. */
 int  mod_dynamic_mask_dev(ModContext *ctx, int32_t frames, const float *vx, const float *vy, const float *vz,
                           uint64_t *dynamic_mask);

@@ -38,7 +38,7 @@ EXPORTS = [
     "mod_cluster_dev", "mod_process_dev", "mod_pack_cloud_dev", "mod_unpack_cloud_dev", "mod_process_frame_host",
     "mod_cluster_cloud_host", "mod_submit_frame_host", "mod_collect_frame_host", "mod_forget_previous", "mod_host_malloc", "mod_host_free",
     "mod_malloc", "mod_free", "mod_memcpy_h2d", "mod_memcpy_d2h", "mod_set_profiling",
-    "mod_get_stage_time", "mod_reset_stage_times",
+    "mod_get_stage_time", "mod_reset_stage_times", "mod_depth_image_dev", "mod_depth_image_host",
 ]
 
 
@@ -120,6 +120,8 @@ def load(require_torch_first: bool = True):
     L.mod_get_params.argtypes = [vp, C.POINTER(ModParams)]
     L.mod_synchronize.argtypes = [vp]
     L.mod_scene_flow_dev.argtypes = [vp, C.POINTER(ModFrameBatch), C.POINTER(ModSceneFlowPlanes)]
+    L.mod_depth_image_dev.argtypes = [vp, i32, vp, vp]
+    L.mod_depth_image_host.argtypes = [vp, vp, vp]
     L.mod_dynamic_mask_dev.argtypes = [vp, i32, vp, vp, vp, vp]
     L.mod_cluster_dev.argtypes = [vp, i32, C.POINTER(ModSceneFlowPlanes), C.POINTER(ModClusterOut)]
     L.mod_process_dev.argtypes = [vp, C.POINTER(ModFrameBatch), C.POINTER(ModSceneFlowPlanes), C.POINTER(ModClusterOut)]

@@ -941,8 +941,6 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     __syncthreads();
     MSTAMP(29)
     if (tid == 0) {
-      if (k == 0 && f == 0) a.dbg[31] += 1;
-      a.dbg[30] += 0;
       ci->med_pix = (int)best; ci->med_bits = val; ci->ambiguous = s_amb;
       if (s_amb) a.tielist[atomicAdd(&a.counters[7], 1)] = item;
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;

@@ -3,6 +3,7 @@
 #include "../../include/mod_sf.h"
 #include "exact_div.h"
 #include "mod_launch.h"
+#include "mod_sf_debug.h"
 
 #include <algorithm>
 #include <cmath>
@@ -147,7 +148,11 @@ void refresh_devcam(ModContext *c) {
   d.mask_words = mod_mask_words(d.W);
   d.n = c->prm.neighbor_distance;
   d.cluster_size = c->prm.cluster_size;
-  { const char *e = getenv("MOD_DEBUG"); d.debug = e ? atoi(e) : 0; }
+#if defined(MOD_PHASE_COUNTERS) || defined(MOD_ABLATION)
+  { const char *e = getenv("MOD_DEBUG"); d.debug = e ? atoi(e) : 0; }   // diagnostic builds only (mod_sf_debug.h)
+#else
+  d.debug = 0;
+#endif
   d.fT = c->cam.disp_f * c->cam.disp_T;               // F32 product, exactly the reference's `focal_length * baseline`
   d.dmin = c->cam.min_disparity; d.dmax = c->cam.max_disparity;
   d.flow_th_sq = sqrt_threshold_sq((float)c->prm.dynamic_flow_diff);
@@ -442,10 +447,29 @@ int mod_synchronize(ModContext *c) {
   return MOD_OK;
 }
 
+// construct() publishes ~depth as soon as disparity_now exists, before the guards that end a frame without scene flow
+// (scene_flow_constructor.cpp:110-123): on a skipped frame the depth plane is still produced when the caller asked for it.
+static int depth_on_skip(ModContext *c, int skip, const ModFrameBatch *in, const ModSceneFlowPlanes *out) {
+  if (skip <= 0 || skip == MOD_SKIP_NO_DISPARITY_NOW || !out || !out->depth || !in->disparity_now) return skip;
+  launch_depth(c->dc, in->frames, in->disparity_now, out->depth, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return skip;
+}
+
 int mod_scene_flow_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out) {
   int rc = check_batch(c, in);
-  if (rc) return rc;
+  if (rc) return depth_on_skip(c, rc, in, out);
   return run_scene_flow(c, in, out, out ? out->dynamic_mask : nullptr);
+}
+
+int mod_depth_image_dev(ModContext *c, int32_t frames, const float *disparity_now, float *depth) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  if (!disparity_now) return MOD_SKIP_NO_DISPARITY_NOW;
+  if (!depth) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null depth plane");
+  launch_depth(c->dc, frames, disparity_now, depth, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
 }
 
 int mod_dynamic_mask_dev(ModContext *c, int32_t frames, const float *vx, const float *vy, const float *vz, uint64_t *mask) {
@@ -466,7 +490,7 @@ int mod_cluster_dev(ModContext *c, int32_t frames, const ModSceneFlowPlanes *pl,
 
 int mod_process_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *pl, const ModClusterOut *out) {
   int rc = check_batch(c, in);
-  if (rc) return rc;
+  if (rc) return depth_on_skip(c, rc, in, pl);
   uint64_t *mask = (pl && pl->dynamic_mask) ? pl->dynamic_mask : c->b.mask;
   rc = run_scene_flow(c, in, pl, mask);
   if (rc) return rc;
@@ -558,6 +582,22 @@ int mod_process_frame_host(ModContext *c, const float *disparity_now, const floa
   if (rc) return rc;
   if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, b.h_aos, 32 * N, hipMemcpyDeviceToHost, c->stream));
   return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
+}
+
+int mod_depth_image_host(ModContext *c, const float *disparity_now, float *depth) {
+  int rc = check_ready(c, 1);
+  if (rc) return rc;
+  if (!disparity_now) return MOD_SKIP_NO_DISPARITY_NOW;
+  if (!depth) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null depth image");
+  if ((rc = ensure_host_staging(c))) return rc;
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  Buffers &b = c->b;
+  HIP_TRY(c, hipMemcpyAsync(b.h_dnow, disparity_now, 4 * N, hipMemcpyHostToDevice, c->stream));
+  launch_depth(c->dc, 1, b.h_dnow, b.h_planes, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(depth, b.h_planes, 4 * N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MOD_OK;
 }
 
 int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int32_t height, int32_t point_step,
@@ -723,7 +763,9 @@ int mod_memcpy_d2h(ModContext *c, void *h, const void *d, uint64_t bytes) {
   return MOD_OK;
 }
 
-// diagnostic: copy an internal buffer to the host (0 members, 1 clusters, 2 counters, 3 cursors)
+#if defined(MOD_PHASE_COUNTERS) || defined(MOD_ABLATION)
+// diagnostic builds only (declared in mod_sf_debug.h; a product build does not export them)
+// copy an internal buffer to the host (0 members, 1 clusters, 2 counters, 3 cursors)
 int mod_debug_read(ModContext *c, int which, void *dst, unsigned long long bytes) {
   if (!c || !dst) return MOD_ERR_INVALID_ARGUMENT;
   const void *src = which == 0 ? (const void *)c->b.mbits : which == 4 ? (const void *)c->b.mpix : which == 1 ? (const void *)c->b.clusters
@@ -741,6 +783,7 @@ int mod_debug_counters(ModContext *c, unsigned long long *out32) {
   HIP_TRY(c, hipMemset((char *)c->b.dbg + 42 * 8, 0xFF, 8));
   return MOD_OK;
 }
+#endif
 
 // ---- measurement -------------------------------------------------------------------------------------------------------
 int mod_set_profiling(ModContext *c, int32_t stage_mask) {

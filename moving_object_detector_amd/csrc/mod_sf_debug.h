@@ -1,0 +1,12 @@
+// mod_sf_debug.h — diagnostic entry points of libmod_sf.so.  NOT part of the product ABI (include/mod_sf.h): they exist only in
+// builds made with `make PHASE_COUNTERS=1` or `make ABLATE=1` (tools/dbg_*.py, tools/ablate.sh), which also read MOD_DEBUG.
+#pragma once
+#if defined(MOD_PHASE_COUNTERS) || defined(MOD_ABLATION)
+#include "../../include/mod_sf.h"
+extern "C" {
+// copy an internal scratch buffer to the host: 0 member norms, 4 member pixels, 1 cluster table, 2 counters, 3 cursors
+int mod_debug_read(ModContext *ctx, int which, void *dst, unsigned long long bytes);
+// 64 cycle / event counters written by the instrumented kernels; reading resets them
+int mod_debug_counters(ModContext *ctx, unsigned long long *out64);
+}
+#endif

@@ -387,6 +387,17 @@ __global__ __launch_bounds__(256) void k_dynamic_mask(DevCam c, const float *__r
   if (lane == 0 && y < c.H && blockIdx.x < (unsigned)c.mask_words) mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x] = w;
 }
 
+// toDepthImage alone (disparity_image_processor.cpp:105-120): construct() publishes ~depth whenever disparity_now exists, also on
+// frames where the flow / the previous disparity / the transform is missing and nothing else is published
+// (scene_flow_constructor.cpp:110-123) — the fused kernel does not run on those.  depth = z of getPoint3D, NaN where it fails.
+__global__ __launch_bounds__(256) void k_depth(DevCam c, size_t n, const float *__restrict__ dnow, float *__restrict__ depth) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float d = dnow[i];
+  const bool ok = disp_in_range(c, d) & !(d == 0.0f);
+  depth[i] = ok ? c.fT / d : __uint_as_float(0x7fc00000u);
+}
+
 // SoA <-> 32-byte AoS (pcl::toROSMsg / fromROSMsg payloads, scene_flow_constructor.cpp:358-361, clusterer_nodelet.cpp:226).
 __global__ __launch_bounds__(256) void k_pack(size_t n, const float *x, const float *y, const float *z, const float *vx,
                                               const float *vy, const float *vz, float4 *aos) {
@@ -423,6 +434,11 @@ void launch_dynamic_mask(const DevCam &c, int frames, const float *vx, const flo
                          hipStream_t s) {
   dim3 block(64, 4, 1), grid((c.W + 63) / 64, (c.H + 3) / 4, frames);
   hipLaunchKernelGGL(k_dynamic_mask, grid, block, 0, s, c, vx, vy, vz, mask);
+}
+
+void launch_depth(const DevCam &c, int frames, const float *dnow, float *depth, hipStream_t s) {
+  const size_t n = (size_t)frames * c.W * c.H;
+  hipLaunchKernelGGL(k_depth, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c, n, dnow, depth);
 }
 
 void launch_pack(size_t n, const float *x, const float *y, const float *z, const float *vx, const float *vy, const float *vz,

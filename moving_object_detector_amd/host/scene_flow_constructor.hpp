@@ -48,7 +48,15 @@ class SceneFlowConstructor {
   bool construct(const mod_host::DisparityImage *disparity_now, const mod_host::DisparityImage *disparity_previous,
                  const mod_host::FlowImage *left_flow, const mod_host::Transform *transform_prev2now,
                  mod_host::PointCloud2 *pc_with_velocity, std::vector<int32_t> *labels = nullptr,
-                 mod_host::MovingObjectArray *moving_objects = nullptr) {
+                 mod_host::MovingObjectArray *moving_objects = nullptr, std::vector<float> *depth_image = nullptr) {
+    // ~depth goes out whenever disparity_now exists, before the guards that end the frame (:110-123)
+    if (depth_image) {
+      depth_image->clear();
+      if (disparity_now) {
+        depth_image->resize((size_t)image_width_ * image_height_);
+        check(mod_depth_image_host(ctx_, disparity_now->data, depth_image->data()));
+      }
+    }
     ModTransform tf{};
     if (transform_prev2now) {
       for (int i = 0; i < 3; i++) tf.t[i] = transform_prev2now->translation[i];

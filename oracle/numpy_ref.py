@@ -65,6 +65,11 @@ def reproject(cam, D):
     return np.where(ok, X, nan), np.where(ok, Y, nan), np.where(ok, z, nan)
 
 
+def depth_image(cam, D):
+    """toDepthImage (disparity_image_processor.cpp:105-120): z of getPoint3D, NaN where it fails."""
+    return reproject(cam, D)[2]
+
+
 def transform_prev(X, Y, Z, t, q):
     """transformPCPreviousToNow: NaN x passes through untouched, else F32(t + R p) with p0 + (p1 + p2) association."""
     R = rotation(q)
@@ -134,6 +139,7 @@ def scene_flow(cam, prm, D_now, D_prev, flow, t, q, dt):
         "vy": np.where(has_v, np.where(moving, vy, zero), nan),
         "vz": np.where(has_v, np.where(moving, vz, zero), nan),
         "static_flow": np.stack([s0, s1], -1),
+        "depth": Zn,
     }
     return out
 

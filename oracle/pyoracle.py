@@ -136,8 +136,22 @@ CLOUD_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("pad0", "f4"), (
                         ("pad1", "f4")])
 
 
+def depth_image(cam, d_now):
+    """~depth: toDepthImage as construct() publishes it even when every other input is missing (the call below hands over
+    only disparity_now and gets the "no flow" skip code back, scene_flow_constructor.cpp:110-123)."""
+    L = lib()
+    H, W = d_now.shape
+    c, p = camera_struct(cam), params_struct(type("P", (), dict(dynamic_flow_diff=5, cluster_size=2500, neighbor_distance=4,
+                                                                 depth_diff=0.15, dynamic_speed=0.3))())
+    d_now = np.ascontiguousarray(d_now, np.float32)
+    depth = np.empty((H, W), np.float32)
+    rc = L.orc_construct_faithful(C.byref(c), C.byref(p), _fp(d_now), None, None, None, 0.0, None, None, _fp(depth))
+    assert rc == 3, rc
+    return depth
+
+
 def construct(cam, prm, d_now, d_prev, flow, t, q, dt, mode="faithful"):
-    """Returns dict of float32 (H,W) planes x,y,z,vx,vy,vz, the 32-byte AoS cloud and the static flow."""
+    """Returns dict of float32 (H,W) planes x,y,z,vx,vy,vz, the 32-byte AoS cloud, the static flow and the depth image."""
     L = lib()
     H, W = d_now.shape
     c, p, tf = camera_struct(cam), params_struct(prm), transform_struct(t, q)
@@ -148,16 +162,19 @@ def construct(cam, prm, d_now, d_prev, flow, t, q, dt, mode="faithful"):
     planes = {k: np.empty((H, W), np.float32) for k in ("x", "y", "z", "vx", "vy", "vz")}
     if mode == "faithful":
         cloud = np.zeros((H, W), CLOUD_DTYPE)
+        depth = np.empty((H, W), np.float32)
         rc = L.orc_construct_faithful(C.byref(c), C.byref(p), _fp(d_now), _fp(d_prev), _fp(flow), C.byref(tf), dt,
-                                      cloud.ctypes.data, _fp(sflow), None)
+                                      cloud.ctypes.data, _fp(sflow), _fp(depth))
         assert rc == 0, rc
         for k in planes:
             planes[k] = np.ascontiguousarray(cloud[k])
+        planes["depth"] = depth
     else:
         rc = L.orc_construct_tidy(C.byref(c), C.byref(p), _fp(d_now), _fp(d_prev), _fp(flow), C.byref(tf), dt,
                                   *[_fp(planes[k]) for k in ("x", "y", "z", "vx", "vy", "vz")], _fp(sflow))
         assert rc == 0, rc
         cloud = pack_cloud(planes)
+        planes["depth"] = depth_image(cam, d_now)
     planes["cloud"] = cloud
     planes["static_flow"] = sflow
     return planes

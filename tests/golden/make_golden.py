@@ -28,7 +28,7 @@ def run_case(name, cam, prm, d_now, d_prev, flow, t, q, dt):
         "d_now": d_now.astype(np.float32), "d_prev": d_prev.astype(np.float32), "flow": flow.astype(np.float32),
         "t": np.asarray(t, np.float64), "q": np.asarray(q, np.float64), "dt": np.float64(dt),
         "labels": labels.astype(np.int32), "K": np.int32(K), "n_objects": np.int32(len(objs)),
-        "static_flow": sf["static_flow"],
+        "static_flow": sf["static_flow"], "depth": sf["depth"],
     }
     for k in ("x", "y", "z", "vx", "vy", "vz"):
         out[k] = sf[k]

@@ -36,6 +36,7 @@ def test_device_path_matches_golden(path):
         got = ws["planes"][i, 0].cpu().numpy()
         assert bits_equal(got, g[k]), (k, first_mismatch(got, g[k]))
     assert bits_equal(ws["static_flow"][0].cpu().numpy(), g["static_flow"])
+    assert bits_equal(ws["depth"][0].cpu().numpy(), g["depth"])
     assert np.array_equal(ws["labels"][0].cpu().numpy(), g["labels"])
     assert int(ws["n_clusters"][0]) == int(np.asarray(g["K"]).item())
     compare_objects(ctx.objects_to_host(ws)[0], golden_objects(g), strict_velocity=False)
@@ -89,6 +90,53 @@ def test_missing_inputs_return_skip_codes():
     assert call(a[0], a[1], a[2], None) == capi.MOD_SKIP_NO_TRANSFORM
     assert call(None, a[1], a[2], tf) == capi.MOD_SKIP_NO_DISPARITY_NOW
     assert call(a[0], a[1], a[2], tf) == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("path", GOLD[:2], ids=[os.path.basename(p) for p in GOLD[:2]])
+def test_depth_is_published_on_skipped_frames(path):
+    """construct() publishes ~depth whenever disparity_now exists, before the guards that end a frame without scene flow
+    (scene_flow_constructor.cpp:110-123): frame 0 of every stream (no flow, no previous disparity) and every frame after an
+    estimator failure still get their depth image; nothing else is written."""
+    from moving_object_detector_amd import capi
+    g, cam, prm = load_case(path)
+    g = {k: np.ascontiguousarray(g[k]) for k in g.files}
+    ctx = _ctx(cam, prm)
+    dev = ctx.device
+    dn, dp, fl = (torch.from_numpy(g[k][None]).to(dev) for k in ("d_now", "d_prev", "flow"))
+    tq = (g["t"][None], g["q"][None], [0.1])
+    cases = [(dn, dp, None, tq, capi.MOD_SKIP_NO_FLOW), (dn, None, fl, tq, capi.MOD_SKIP_NO_DISPARITY_PREV),
+             (dn, dp, fl, (None, None, None), capi.MOD_SKIP_NO_TRANSFORM), (dn, None, None, (None, None, None), capi.MOD_SKIP_NO_FLOW)]
+    for fused in (True, False):
+        for a, b_, c_, (t, q, dt), code in cases:
+            ws = ctx.workspace(1, aos=True, extras=True)
+            ws["depth"].fill_(-7.0)
+            ws["planes"].fill_(-7.0)
+            ws["labels"].fill_(-7)
+            b = ctx.make_batch(a, b_, c_, t, q, dt)
+            rc = ctx.process(b, ws) if fused else ctx.scene_flow(b, ws)
+            assert rc == code
+            ctx.synchronize()
+            assert bits_equal(ws["depth"][0].cpu().numpy(), g["depth"])
+            assert bool((ws["planes"] == -7.0).all()) and bool((ws["labels"] == -7).all())      # nothing else is published
+    # no disparity_now: nothing at all
+    ws["depth"].fill_(-7.0)
+    assert ctx.process(ctx.make_batch(dn, dp, fl, *tq), ws) == 0          # (sanity: the complete frame runs)
+    b = ctx.make_batch(dn, dp, fl, *tq)
+    b.disparity_now = None
+    ws["depth"].fill_(-7.0)
+    assert ctx.process(b, ws) == capi.MOD_SKIP_NO_DISPARITY_NOW
+    ctx.synchronize()
+    assert bool((ws["depth"] == -7.0).all())
+    # the stand-alone forms: device planes and one host frame
+    out = torch.empty_like(dn)
+    assert ctx.lib.mod_depth_image_dev(ctx.h, 1, dn.data_ptr(), out.data_ptr()) == 0
+    ctx.synchronize()
+    assert bits_equal(out[0].cpu().numpy(), g["depth"])
+    host = np.full(g["d_now"].shape, -7.0, np.float32)
+    assert ctx.lib.mod_depth_image_host(ctx.h, g["d_now"].ctypes.data, host.ctypes.data) == 0
+    assert bits_equal(host, g["depth"])
+    assert ctx.lib.mod_depth_image_host(ctx.h, None, host.ctypes.data) == capi.MOD_SKIP_NO_DISPARITY_NOW
     ctx.close()
 
 

@@ -82,6 +82,7 @@ def test_1280x720_reference_defaults(oracle):
         for j, k in zip((0, 1, 2, 4, 5, 6), PLANES):
             assert bits_equal(aos[..., j], ref[k])
         assert bits_equal(out["static_flow"][f], ref["static_flow"])
+        assert bits_equal(out["depth"][f], ref["depth"]), first_mismatch(out["depth"][f], ref["depth"])   # ~depth (toDepthImage)
 
 
 @pytest.mark.parametrize("n", [1, 4, 10])
@@ -145,3 +146,19 @@ def test_kitti_style_camera(oracle):
     prm = synth.Params(cluster_size=300)
     out = _run_gpu(cam, prm, batch)
     _check_against_oracle(oracle, cam, prm, batch, out)
+
+
+def test_kitti_style_camera_1280x720_sequence(oracle):
+    """Config 3 at its stated size: a 1280x720 KITTI-style *sequence* (frame t's now-disparity is frame t+1's previous, one
+    buffer of F+1 planes: prev = D, now = D + H*W), reference default parameters."""
+    from moving_object_detector_amd import synth
+    cam, seq = synth.make_sequence(1280, 720, 3, seed=31, camera="kitti")
+    batch = {"disparity_now": seq["disparity"][1:], "disparity_prev": seq["disparity"][:-1], "flow": seq["flow"],
+             "t": seq["t"], "q": seq["q"], "dt": seq["dt"]}
+    batch = {k: np.ascontiguousarray(v) for k, v in batch.items()}
+    prm = synth.Params()
+    out = _run_gpu(cam, prm, batch, extras=True)
+    _check_against_oracle(oracle, cam, prm, batch, out)
+    assert sum(len(o) for o in out["objects"]) > 0
+    for f in range(3):
+        assert bits_equal(out["depth"][f], oracle.depth_image(cam, batch["disparity_now"][f]))
