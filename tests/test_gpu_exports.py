@@ -60,7 +60,7 @@ def test_device_memory_helpers_carry_a_whole_frame(oracle):
     W, H = 160, 120
     cam, batch = synth.make_batch(W, H, 1, seed=22)
     prm = synth.Params(dynamic_flow_diff=1, cluster_size=60)
-    ctx = Context(W, H, max_frames=1, use_torch_stream=False)          # the context's own stream
+    ctx = Context(W, H, max_frames=1, max_objects=W * H // 60 + 1, use_torch_stream=False)   # the context's own stream
     ctx.set_camera(cam)
     ctx.set_params(prm)
     L, h, N = ctx.lib, ctx.h, W * H
