@@ -96,9 +96,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 // Adds the members of one wave (grouped by the record they belong to) into the statistics records with one set of
-// atomics per (wave, record).  `rec_idx` < 0 marks a lane without contribution.
-__device__ __forceinline__ void wave_accumulate(CompRec *recs, int rec_idx, uint32_t key, uint32_t ox, uint32_t oy, uint32_t oz,
-                                                int lane) {
+// atomics per (wave, record).  `rec_idx` < 0 marks a lane without contribution.  Works on LDS slots and on the global planes.
+__device__ __forceinline__ void wave_accumulate(int *sizes, int *keys, int stride, int rec_idx, uint32_t key, int lane) {
   uint64_t todo = __ballot(rec_idx >= 0);
   while (todo) {
     const int leader = __ffsll((unsigned long long)todo) - 1;
@@ -106,16 +105,9 @@ __device__ __forceinline__ void wave_accumulate(CompRec *recs, int rec_idx, uint
     const bool mine = rec_idx == lid;
     const uint64_t grp = __ballot(mine);
     const uint32_t k = wave_min_u32(mine ? key : (uint32_t)kKeyNone);
-    const uint32_t mnx = wave_min_u32(mine ? ox : 0xffffffffu), mxx = wave_max_u32(mine ? ox : 0u);
-    const uint32_t mny = wave_min_u32(mine ? oy : 0xffffffffu), mxy = wave_max_u32(mine ? oy : 0u);
-    const uint32_t mnz = wave_min_u32(mine ? oz : 0xffffffffu), mxz = wave_max_u32(mine ? oz : 0u);
     if (lane == leader) {
-      CompRec *r = recs + lid;
-      atomicAdd(&r->size, __popcll((unsigned long long)grp));
-      if (k != (uint32_t)kKeyNone) atomicMin(&r->key, (int)k);
-      atomicMin(&r->mn[0], mnx); atomicMax(&r->mx[0], mxx);
-      atomicMin(&r->mn[1], mny); atomicMax(&r->mx[1], mxy);
-      atomicMin(&r->mn[2], mnz); atomicMax(&r->mx[2], mxz);
+      atomicAdd(&sizes[(size_t)lid * stride], __popcll((unsigned long long)grp));
+      if (k != (uint32_t)kKeyNone) atomicMin(&keys[(size_t)lid * stride], (int)k);
     }
     todo &= ~grp;
   }
@@ -181,7 +173,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __shared__ uint64_t m0[PH], mL[PH];
   constexpr int kSlots = 32;
   __shared__ int s_any, s_nreq, s_nslots;
-  __shared__ CompRec srec[kSlots];
+  __shared__ RootRec srec[kSlots];
   __shared__ int sroot[kSlots];
   // threadIdx.y is the wave index: the same in all 64 lanes, but it arrives in a vector register — as a scalar, every row
   // index derived from it stays on the scalar unit
@@ -227,14 +219,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // All HBM reads of the kernel are issued here, unconditionally (clamped addresses, values of non-dynamic pixels are
   // discarded): predicated loads would compile to one exec-masked branch + wait each, i.e. one round trip per row.
   constexpr int AROWS = (PH + NW - 1) / NW;
-  float xr[RPW], yr[RPW], zl[AROWS], zh[AROWS];
+  float zl[AROWS], zh[AROWS];
   const int xc = min(x0 + lane, c.W - 1), xhc = max(x0 - 1 - lane, 0);
-#pragma unroll
-  for (int j = 0; j < RPW; j++) {
-    const size_t gp = fN + (size_t)min(y0 + w + NW * j, c.H - 1) * c.W + xc;
-    xr[j] = a.x[gp];
-    yr[j] = a.y[gp];
-  }
 #pragma unroll
   for (int i = 0; i < AROWS; i++) {
     const int gy = min(max(y0 - NMAX + w + NW * i, 0), c.H - 1);
@@ -467,12 +453,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const bool isroot = (rootbits[j] >> lane) & 1ull;
     if (isroot) {
       const int slot = atomicAdd(&s_nslots, 1);
-      CompRec rec;
+      RootRec rec;
       rec.size = 0; rec.key = kKeyNone;
-      rec.mn[0] = rec.mn[1] = rec.mn[2] = 0xffffffffu;
-      rec.mx[0] = rec.mx[1] = rec.mx[2] = 0u;
       if (slot < kSlots) { srec[slot] = rec; sroot[slot] = rootg[j]; Lt[rootc[j]] = -(slot + 1); }
-      else a.comps[fN + rootg[j]] = rec;
+      else { a.rsize[fN + rootg[j]] = 0; a.rkey[fN + rootg[j]] = kKeyNone; }
     }
   }
   lds_barrier();     // slot tags visible
@@ -483,22 +467,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int rr = w + NW * j, gy = y0 + rr;
     if (m0[rr + NMAX] == 0 || MOD_ABLATE(c, 520)) continue;                // wave-uniform
     const int rg = rootg[j];
-    uint32_t ox = 0, oy = 0, oz = 0, key = (uint32_t)kKeyNone;
+    uint32_t key = (uint32_t)kKeyNone;
     int slot = -1, over = -1;
     if (rg >= 0) {
       const size_t gp = (size_t)gy * c.W + x0 + lane;
-      ox = f2ord(xr[j]); oy = f2ord(yr[j]); oz = f2ord(zt[(rr + NMAX) * PW + NMAX + lane]);
       if (upr[j]) key = (uint32_t)gp;
       const int tag = Lt[rootc[j]];
       if (tag < 0) slot = -tag - 1; else over = rg;
     }
-    wave_accumulate(srec, slot, key, ox, oy, oz, lane);
-    if (__ballot(over >= 0)) wave_accumulate(a.comps + fN, over, key, ox, oy, oz, lane);
+    wave_accumulate(&srec[0].size, &srec[0].key, 2, slot, key, lane);
+    if (__ballot(over >= 0)) wave_accumulate(a.rsize + fN, a.rkey + fN, 1, over, key, lane);
   }
   lds_barrier();
   {
     const int ns = min(s_nslots, kSlots);
-    if (tid < ns) a.comps[fN + sroot[tid]] = srec[tid];
+    if (tid < ns) { a.rsize[fN + sroot[tid]] = srec[tid].size; a.rkey[fN + sroot[tid]] = srec[tid].key; }
   }
   STAMP(8)
 #undef STAMP
@@ -556,7 +539,7 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
   const int t = (blockIdx.x * 4 + wv) * TPW + lane / TH, j = lane % TH;
   const size_t N = (size_t)c.W * c.H;
   int *parent = a.parent + (size_t)f * N;
-  CompRec *recs = a.comps + (size_t)f * N;
+  int *rsize = a.rsize + (size_t)f * N, *rkey = a.rkey + (size_t)f * N;
   if (t >= tiles_per_frame || a.tilehdr[((size_t)f * tiles_per_frame + t) * 2] == 0) return;   // nothing dynamic in the tile
   const int wi = t % c.mask_words, ty = t / c.mask_words, y = ty * TH + j;
   if (y >= c.H) return;
@@ -571,13 +554,9 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
       a.rootlist[(size_t)f * N + slot] = p;
     } else {
       parent[p] = r;   // r is final: no union runs after k_ccl_link
-      const CompRec rec = recs[p];
-      CompRec *t2 = recs + r;
-      atomicAdd(&t2->size, rec.size);
-      if (rec.key != kKeyNone) atomicMin(&t2->key, rec.key);
-      atomicMin(&t2->mn[0], rec.mn[0]); atomicMax(&t2->mx[0], rec.mx[0]);
-      atomicMin(&t2->mn[1], rec.mn[1]); atomicMax(&t2->mx[1], rec.mx[1]);
-      atomicMin(&t2->mn[2], rec.mn[2]); atomicMax(&t2->mx[2], rec.mx[2]);
+      const int sz = rsize[p], ky = rkey[p];
+      atomicAdd(&rsize[r], sz);
+      if (ky != kKeyNone) atomicMin(&rkey[r], ky);
     }
   }
 }
@@ -591,7 +570,7 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
   __syncthreads();
   const size_t N = (size_t)c.W * c.H;
   const int nroots = a.counters[f * 8 + 0];
-  CompRec *recs = a.comps + (size_t)f * N;
+  int *rsize = a.rsize + (size_t)f * N, *rkey = a.rkey + (size_t)f * N;
   const int *roots = a.rootlist + (size_t)f * N;
   ClusterInfo *T = tmp + (size_t)f * a.max_objects;
   ClusterInfo *C = a.clusters + (size_t)f * a.max_objects;
@@ -599,14 +578,14 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
   // a component without any edge never got a label in the reference (key == none)
   for (int i = tid; i < nroots; i += 256) {
     const int r = roots[i];
-    const int size = recs[r].size, key = recs[r].key;
+    const int size = rsize[r], key = rkey[r];
     bool keep = (key != kKeyNone) && (size >= c.cluster_size);
     if (keep) {
       const int slot = atomicAdd(&s_n, 1);
       if (slot < a.max_objects) { T[slot].comp = r; T[slot].size = size; T[slot].offset = key; }
       else { a.counters[f * 8 + 3] = 2; keep = false; }   // more clusters than max_objects: the excess is dropped (flagged)
     }
-    if (!keep) recs[r].key = -1;
+    if (!keep) rkey[r] = -1;
   }
   __syncthreads();
   const int K = min(s_n, a.max_objects);
@@ -619,8 +598,11 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
     ci.comp = T[s].comp; ci.size = T[s].size; ci.offset = 0; ci.med_pix = -1; ci.med_bits = 0; ci.ambiguous = 0;
     ci.pad[0] = ci.pad[1] = 0;
     C[rank] = ci;
-    recs[ci.comp].key = rank;
+    rkey[ci.comp] = rank;                               // k_final looks the new label up here
     a.cursors[(size_t)f * a.max_objects + rank] = 0;
+    ClusterBox bx;
+    for (int d = 0; d < 8; d++) bx.w[d] = 0xffffffffu;
+    a.cbox[(size_t)f * a.max_objects + rank] = bx;      // k_final folds the members' x, y, z into it
   }
   __syncthreads();
   if (tid == 0) {
@@ -632,18 +614,12 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
     const int base = K ? atomicAdd(&a.counters[6], K) : 0;
     for (int k = 0; k < K; k++) a.worklist[base + k] = (uint32_t)f * (uint32_t)a.max_objects + (uint32_t)k;
   }
-  // bbox / centre (cluster2MovingObject, clusterer_nodelet.cpp:151-161): F32 max-min and (min+max)/2, widened to F64
+  // object shells; bounding_box / center / velocity are filled by k_median once k_final has folded the members' coordinates
   ModObject *O = (ModObject *)a.objects + (size_t)f * a.max_objects;
   for (int k = tid; k < K; k += 256) {
-    const CompRec r = recs[C[k].comp];
     ModObject o;
-    o.id = k; o.n_points = r.size;
-    for (int d = 0; d < 3; d++) {
-      const float mn = ord2f(r.mn[d]), mx = ord2f(r.mx[d]);
-      o.bounding_box[d] = (double)(mx - mn);
-      o.center[d] = (double)((mn + mx) / 2.0f);
-      o.velocity[d] = 0.0;
-    }
+    o.id = k; o.n_points = C[k].size;
+    for (int d = 0; d < 3; d++) { o.bounding_box[d] = 0.0; o.center[d] = 0.0; o.velocity[d] = 0.0; }
     o.orientation[0] = 0.0; o.orientation[1] = 0.0; o.orientation[2] = 0.0; o.orientation[3] = 1.0;
     O[k] = o;
   }
@@ -685,7 +661,7 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   for (int j = 0; j < RPW; j++) {
     if ((rw[j] >> lane) & 1ull) {
       const int cell = (r0 + j) * 64 + lane;
-      nlmap[cell] = a.comps[fN + par[j]].key;
+      nlmap[cell] = a.rkey[fN + par[j]];
       lcount[cell] = 0;
     }
   }
@@ -729,13 +705,14 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
       else if (l >= 0) rank[j] = atomicAdd(&lcount[cl], 1);
     }
   }
-  // velocity of the wave's members (needed for the ||v|| bits), in flight across the barriers
-  float vx[RPW], vy[RPW], vz[RPW];
+  // velocity (for the ||v|| bits) and coordinates (for the bounding box) of the wave's members, in flight across the barriers
+  float vx[RPW], vy[RPW], vz[RPW], px[RPW], py[RPW], pz[RPW];
   if (any_member) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       const size_t gp = fN + (size_t)min(y0 + r0 + j, c.H - 1) * c.W + xc;
       vx[j] = a.vx[gp]; vy[j] = a.vy[gp]; vz[j] = a.vz[gp];
+      px[j] = a.x[gp]; py[j] = a.y[gp]; pz[j] = a.z[gp];
     }
   }
   lds_barrier();
@@ -758,6 +735,35 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
         a.mbits[slot] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
         a.mpix[slot] = (uint32_t)((y0 + r0 + j) * c.W + x);
       }
+    }
+    // bounding box of the cluster (pcl::getMinMax3D in cluster2MovingObject, clusterer_nodelet.cpp:151-152): the wave's members
+    // are folded per cluster label with DPP reductions, one set of atomics per (wave, cluster) — nearly always one cluster
+    int pend[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) pend[j] = nl[j];
+    for (;;) {
+      int mine = -1;
+#pragma unroll
+      for (int j = 0; j < RPW; j++) mine = pend[j] >= 0 ? pend[j] : mine;
+      const uint64_t b = __ballot(mine >= 0);
+      if (b == 0) break;                               // wave-uniform
+      const int L = __builtin_amdgcn_readlane(mine, __ffsll((unsigned long long)b) - 1);
+      uint32_t mn0 = 0xffffffffu, mn1 = 0xffffffffu, mn2 = 0xffffffffu, mx0 = 0u, mx1 = 0u, mx2 = 0u;
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        if (pend[j] == L) {
+          const uint32_t ox = f2ord(px[j]), oy = f2ord(py[j]), oz = f2ord(pz[j]);
+          mn0 = min(mn0, ox); mx0 = max(mx0, ox); mn1 = min(mn1, oy); mx1 = max(mx1, oy); mn2 = min(mn2, oz); mx2 = max(mx2, oz);
+          pend[j] = -1;
+        }
+      }
+      mn0 = wave_min_u32(mn0); mn1 = wave_min_u32(mn1); mn2 = wave_min_u32(mn2);
+      mx0 = wave_max_u32(mx0); mx1 = wave_max_u32(mx1); mx2 = wave_max_u32(mx2);
+      // ONE atomic instruction per (wave, cluster): lanes 0..5 each fold one word (an atomic instruction costs the CU's memory
+      // pipeline the same whether one lane or six are active); the maxima are kept complemented so that all six are minima
+      uint32_t v = ~mx2;
+      v = lane == 0 ? mn0 : v; v = lane == 1 ? mn1 : v; v = lane == 2 ? mn2 : v; v = lane == 3 ? ~mx0 : v; v = lane == 4 ? ~mx1 : v;
+      if (lane < 6) atomicMin(&a.cbox[(size_t)f * a.max_objects + L].w[lane], v);
     }
   }
 }
@@ -808,7 +814,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     const int size = ci->size;
     const uint32_t *sbits = a.mbits + (size_t)f * N + ci->offset;   // ||v|| bits of the members ...
     const uint32_t *spix = a.mpix + (size_t)f * N + ci->offset;     // ... and their pixel indices
-    const CompRec rec = a.comps[(size_t)f * N + ci->comp];          // for the NaN test at the end; in flight meanwhile
+    const ClusterBox rec = a.cbox[(size_t)f * a.max_objects + k];   // complete: k_final has finished; in flight meanwhile
 #ifdef MOD_PHASE_COUNTERS
     unsigned long long mt0 = wall_clock64(), mt1;
 #define MSTAMP(i) { __syncthreads(); mt1 = wall_clock64(); if (tid == 0) atomicAdd(&a.dbg[i], mt1 - mt0); mt0 = mt1; }
@@ -945,6 +951,12 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
       if (s_amb) a.tielist[atomicAdd(&a.counters[7], 1)] = item;
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
       o->velocity[0] = (double)bvx; o->velocity[1] = (double)bvy; o->velocity[2] = (double)bvz;
+      // bbox / centre (cluster2MovingObject, clusterer_nodelet.cpp:151-161): F32 max-min and (min+max)/2, widened to F64
+      for (int d = 0; d < 3; d++) {
+        const float mn = ord2f(rec.w[d]), mx = ord2f(~rec.w[3 + d]);
+        o->bounding_box[d] = (double)(mx - mn);
+        o->center[d] = (double)((mn + mx) / 2.0f);
+      }
     }
     __syncthreads();
     // ---- NaN coordinates among the members (only possible for caller-supplied clouds: the scene-flow stage never marks a
@@ -953,7 +965,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     // the NaN, i.e. the result is the min / max over the members AFTER the last NaN, or NaN when the last member is NaN.
     {
       bool anynan = false;
-      for (int d = 0; d < 3; d++) anynan = anynan || isnan(ord2f(rec.mn[d])) || isnan(ord2f(rec.mx[d]));
+      for (int d = 0; d < 3; d++) anynan = anynan || isnan(ord2f(rec.w[d])) || isnan(ord2f(~rec.w[3 + d]));
       if (anynan) {                                  // block-uniform
         const float *pl[3] = {a.x + (size_t)f * N, a.y + (size_t)f * N, a.z + (size_t)f * N};
         for (int d = 0; d < 3; d++) {
@@ -992,7 +1004,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
 // its k-th swap exchanges the k-th element from the left that is not before the pivot with the k-th from the right that is
 // not after it, so ranks from two prefix counts give every swap at once — and the finished (<= 16 element) range gets the
 // stable insertion sort.  Rare path: one workgroup per flagged cluster, nothing to do for the others.
-// Scratch (all dead by now): keys -> parent plane, pixels -> comps region, swap lists -> the member arrays.
+// Scratch (all dead by now): keys -> parent plane, pixels -> rsize plane, swap lists -> the member arrays.
 constexpr int kTieThreads = 1024, kTieCols = 2048, kTieLds = 8192;
 
 struct TieShared {           // control block of one workgroup of k_median_ties
@@ -1146,7 +1158,7 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
 #endif
     const int size = ci->size, off = ci->offset;
     uint32_t *key = (uint32_t *)(a.parent + fN) + off;
-    uint32_t *val = (uint32_t *)(a.comps + fN) + off;
+    uint32_t *val = (uint32_t *)(a.rsize + fN) + off;
     uint32_t *Apos = a.mbits + fN + off, *Bpos = a.mpix + fN + off;
     // ---- image-space bounding box of the cluster (from its member list, before that list becomes scratch) ----
     if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0; s_box[2] = 0x7fffffff; s_box[3] = 0; }

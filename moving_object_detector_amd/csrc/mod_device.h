@@ -43,17 +43,23 @@ struct FrameConst {
                            // [1]: RN(1/dt), [2]: 1 when [1] may replace the division by dt (exact_div.h), else 0
 };
 
-// Per-component record (32 bytes).  Filled by the stats kernel with wave-aggregated atomics.
-struct CompRec {
-  int32_t size;        // member count
-  int32_t key;         // first_edge_key (min raster index of a member with an up-left edge); later: new label or -1
-  uint32_t mn[3];      // ordered-uint encodings of min x,y,z
-  uint32_t mx[3];      // ordered-uint encodings of max x,y,z
+// Per-component statistics live in two sparse planes indexed by the root's pixel index (ClArgs.rsize / rkey): member count
+// and first_edge_key (min raster index of a member with an up-left edge; after k_select: new label or -1).  RootRec is the
+// LDS form of one such record while a tile reduces its components.
+struct RootRec {
+  int32_t size;
+  int32_t key;
+};
+
+// Bounding box of a surviving cluster (ordered-uint encodings, f2ord): accumulated by k_final (one 6-lane atomic per wave), turned into the object's
+// bounding_box / center by k_median.  32 bytes.
+struct ClusterBox {
+  uint32_t w[8];       // [0..2] min x, y, z; [3..5] COMPLEMENT of max x, y, z (so that every word is folded with atomicMin); [6..7] pad
 };
 
 // Per surviving cluster (after the size filter), in label order.
 struct ClusterInfo {
-  int32_t comp;        // component id (index into CompRec)
+  int32_t comp;        // component id = pixel index of its final root
   int32_t size;
   int32_t offset;      // start of its member segment
   int32_t med_pix;     // pixel index of the member chosen as the median-velocity element

@@ -20,7 +20,9 @@ struct ClArgs {
   int32_t *parent;            // [F][N] union-find parents (only dynamic entries are ever touched)
   int32_t *rootlist;          // [F][N] pixel indices of the final roots (aliases `mpix`, dead before k_final)
   int32_t *labels;            // [F][N] output plane; used as the root/code plane in between
-  CompRec *comps;             // [F][N] statistics records, indexed by the root's pixel index (sparsely touched)
+  int32_t *rsize;             // [F][N] member count of the component rooted at this pixel (sparse: only root entries are touched)
+  int32_t *rkey;              // [F][N] its first_edge_key; after k_select the new label of a final root, or -1
+  ClusterBox *cbox;           // [F][max_objects] bounding boxes of the surviving clusters (k_select init, k_final atomics)
   int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects, 3 overflow flags
   ClusterInfo *clusters;      // [F][max_objects]
   uint32_t *mbits;            // [F][N] ||v|| bit patterns of the members, grouped per cluster (SoA with mpix)

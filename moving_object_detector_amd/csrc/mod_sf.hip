@@ -25,7 +25,8 @@ struct Buffers {
   FrameConst *fc = nullptr;                 // [maxF]
   uint64_t *mask = nullptr, *lroot = nullptr;
   int32_t *parent = nullptr;
-  CompRec *comps = nullptr;
+  int32_t *rsize = nullptr, *rkey = nullptr;
+  ClusterBox *cbox = nullptr;
   int32_t *counters = nullptr;
   ClusterInfo *clusters = nullptr;          // 2 x [maxF][max_objects]
   uint32_t *mbits = nullptr, *mpix = nullptr;
@@ -269,7 +270,7 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   ClArgs a;
   a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
   a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.mpix;
-  a.labels = out->labels; a.comps = c->b.comps; a.counters = c->b.counters; a.clusters = c->b.clusters;
+  a.labels = out->labels; a.rsize = c->b.rsize; a.rkey = c->b.rkey; a.cbox = c->b.cbox; a.counters = c->b.counters; a.clusters = c->b.clusters;
   a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.cursors = c->b.cursors; a.worklist = c->b.worklist; a.tielist = c->b.worklist + (size_t)c->cfg.max_frames * c->max_objects;
   a.objects = out->objects; a.n_objects = out->n_objects;
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
@@ -328,7 +329,9 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   ok &= dalloc(&c->b.mask, mw) == hipSuccess;
   ok &= dalloc(&c->b.lroot, mw) == hipSuccess;
   ok &= dalloc(&c->b.parent, (size_t)F * N) == hipSuccess;
-  ok &= dalloc(&c->b.comps, (size_t)F * N) == hipSuccess;   // 32 B per pixel of address space, touched only at roots
+  ok &= dalloc(&c->b.rsize, (size_t)F * N) == hipSuccess;   // 4 + 4 B per pixel of address space, touched only at roots
+  ok &= dalloc(&c->b.rkey, (size_t)F * N) == hipSuccess;
+  ok &= dalloc(&c->b.cbox, (size_t)F * c->max_objects) == hipSuccess;
   ok &= dalloc(&c->b.counters, (size_t)F * 8) == hipSuccess;
   ok &= dalloc(&c->b.clusters, (size_t)2 * F * c->max_objects) == hipSuccess;
   ok &= dalloc(&c->b.mbits, (size_t)F * N) == hipSuccess;
@@ -356,7 +359,7 @@ void mod_destroy(ModContext *c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
-  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.comps, b.counters, b.clusters, b.mbits, b.mpix,
+  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.rsize, b.rkey, b.cbox, b.counters, b.clusters, b.mbits, b.mpix,
                  b.cursors, b.worklist, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
