@@ -173,6 +173,27 @@ int  mod_process_dev(ModContext *ctx, const ModFrameBatch *in, const ModSceneFlo
 int  mod_pack_cloud_dev(ModContext *ctx, int32_t frames, const ModSceneFlowPlanes *planes, void *cloud_aos);
 int  mod_unpack_cloud_dev(ModContext *ctx, int32_t frames, const void *cloud_aos, const ModSceneFlowPlanes *planes);
 
+/* ---- on-GPU disparity: FIRST STAGES, the estimator is not complete yet ------------------------------ */
+/* The reference obtains disparity_now from sgm_gpu::SgmGpu::computeDisparity(left, right, left_info, right_info, disparity)
+ * (scene_flow_constructor/src/scene_flow_constructor.cpp:35,267; package sgm_gpu of sgm_gpu_ros, not vendored).  Algorithm and
+ * parameters: oracle/sgm_ref.cpp.  Available so far: the census transform and the two horizontal aggregation paths; the remaining
+ * six paths, winner-take-all, median and the left-right check follow.  Planes are [frames][H][W] of the
+ * configured camera size; cost volumes are [frames][H][W][disparities] uint8. */
+#define MOD_SGM_MAX_DISPARITIES 128
+typedef struct ModSgmParams {
+  int32_t disparities;   /* D <= 128; default 128 */
+  int32_t p1, p2;        /* smoothness penalties; defaults 6, 96; 31 + p2 must fit uint8 */
+  int32_t paths;         /* 8 (or 4) — recorded for the complete estimator */
+  int32_t lr_check;      /* left-right consistency check, tolerance 1 */
+  int32_t median;        /* 3 x 3 median of the winner-take-all map */
+} ModSgmParams;
+/* centre-symmetric 9 x 7 census of 8-bit images, 31 bits per pixel (0 where the window leaves the image) */
+int  mod_sgm_census_dev(ModContext *ctx, int32_t frames, const uint8_t *image, uint32_t *census);
+/* one aggregation path L_r over the Hamming cost of the census words; direction 0 = left to right, 1 = right to left (others:
+ * MOD_ERR_INVALID_ARGUMENT for now).  matching_cost (optional) receives C itself. */
+int  mod_sgm_path_dev(ModContext *ctx, int32_t frames, const uint32_t *census_left, const uint32_t *census_right,
+                      const ModSgmParams *params, int32_t direction, uint8_t *path_cost, uint8_t *matching_cost);
+
 /* ---- host-pointer convenience (what a ROS node with host-side messages calls) ----------------------------- */
 /* One frame, host buffers in/out; any output pointer may be NULL.  Returns a skip code exactly where construct()
  * would publish nothing.  cloud_aos: W*H*32 bytes; labels: W*H int32; objects: capacity `max_objects`. */

@@ -39,6 +39,7 @@ EXPORTS = [
     "mod_cluster_cloud_host", "mod_submit_frame_host", "mod_collect_frame_host", "mod_forget_previous", "mod_host_malloc", "mod_host_free",
     "mod_malloc", "mod_free", "mod_memcpy_h2d", "mod_memcpy_d2h", "mod_set_profiling",
     "mod_get_stage_time", "mod_reset_stage_times", "mod_depth_image_dev", "mod_depth_image_host",
+    "mod_sgm_census_dev", "mod_sgm_path_dev",
 ]
 
 
@@ -76,6 +77,11 @@ class ModSceneFlowPlanes(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("z", C.c_void_p), ("vx", C.c_void_p), ("vy", C.c_void_p),
                 ("vz", C.c_void_p), ("dynamic_mask", C.c_void_p), ("cloud_aos", C.c_void_p), ("depth", C.c_void_p),
                 ("static_flow", C.c_void_p)]
+
+
+class ModSgmParams(C.Structure):
+    _fields_ = [("disparities", C.c_int32), ("p1", C.c_int32), ("p2", C.c_int32), ("paths", C.c_int32), ("lr_check", C.c_int32),
+                ("median", C.c_int32)]
 
 
 class ModClusterOut(C.Structure):
@@ -122,6 +128,8 @@ def load(require_torch_first: bool = True):
     L.mod_scene_flow_dev.argtypes = [vp, C.POINTER(ModFrameBatch), C.POINTER(ModSceneFlowPlanes)]
     L.mod_depth_image_dev.argtypes = [vp, i32, vp, vp]
     L.mod_depth_image_host.argtypes = [vp, vp, vp]
+    L.mod_sgm_census_dev.argtypes = [vp, i32, vp, vp]
+    L.mod_sgm_path_dev.argtypes = [vp, i32, vp, vp, C.POINTER(ModSgmParams), i32, vp, vp]
     L.mod_dynamic_mask_dev.argtypes = [vp, i32, vp, vp, vp, vp]
     L.mod_cluster_dev.argtypes = [vp, i32, C.POINTER(ModSceneFlowPlanes), C.POINTER(ModClusterOut)]
     L.mod_process_dev.argtypes = [vp, C.POINTER(ModFrameBatch), C.POINTER(ModSceneFlowPlanes), C.POINTER(ModClusterOut)]

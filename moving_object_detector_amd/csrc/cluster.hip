@@ -69,32 +69,6 @@ __device__ __forceinline__ int uf_unite(int *parent, int a, int b) {
   }
 }
 
-// Wave-wide min/max: four DPP steps reduce each row of 16 lanes (quad swaps, half-row mirror, row mirror), four
-// v_readlane + scalar ops combine the rows.  All 64 lanes must be active.  ~11 instructions, no LDS traffic.
-#define MOD_DPP(v, ctrl) (uint32_t) __builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, 0xF, 0xF, false)
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-  uint32_t t;
-  t = MOD_DPP(v, 0xB1); v = t < v ? t : v;     // quad_perm [1,0,3,2]
-  t = MOD_DPP(v, 0x4E); v = t < v ? t : v;     // quad_perm [2,3,0,1]
-  t = MOD_DPP(v, 0x141); v = t < v ? t : v;    // row_half_mirror
-  t = MOD_DPP(v, 0x140); v = t < v ? t : v;    // row_mirror
-  const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
-  return ab < cd ? ab : cd;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-  uint32_t t;
-  t = MOD_DPP(v, 0xB1); v = t > v ? t : v;
-  t = MOD_DPP(v, 0x4E); v = t > v ? t : v;
-  t = MOD_DPP(v, 0x141); v = t > v ? t : v;
-  t = MOD_DPP(v, 0x140); v = t > v ? t : v;
-  const uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-  const uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-  return ab > cd ? ab : cd;
-}
-
 // Adds the members of one wave (grouped by the record they belong to) into the statistics records with one set of
 // atomics per (wave, record).  `rec_idx` < 0 marks a lane without contribution.  Works on LDS slots and on the global planes.
 __device__ __forceinline__ void wave_accumulate(int *sizes, int *keys, int stride, int rec_idx, uint32_t key, int lane) {

@@ -57,3 +57,8 @@ void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 int ccl_tile_rows();                 // tile height of k_ccl_tile
 int ccl_request_capacity(int n);     // link requests one tile can emit at neighbor_distance n
+
+// on-GPU disparity, first stages (sgm.hip)
+void launch_sgm_census(int W, int H, int frames, const uint8_t *img, uint32_t *out, hipStream_t s);
+void launch_sgm_path_h(int W, int H, int frames, int D, int P1, int P2, bool right_to_left, const uint32_t *cl, const uint32_t *cr,
+                       uint8_t *L, uint8_t *cost, hipStream_t s);

@@ -518,6 +518,31 @@ int mod_unpack_cloud_dev(ModContext *c, int32_t frames, const void *aos, const M
   return MOD_OK;
 }
 
+// ---- on-GPU disparity, first stages ---------------------------------------------------------------
+int mod_sgm_census_dev(ModContext *c, int32_t frames, const uint8_t *image, uint32_t *census) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  if (!image || !census) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null image / census plane");
+  launch_sgm_census(c->dc.W, c->dc.H, frames, image, census, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left, const uint32_t *census_right, const ModSgmParams *p,
+                     int32_t direction, uint8_t *path_cost, uint8_t *matching_cost) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  if (!census_left || !census_right || !p || !path_cost) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null plane / parameters");
+  if (p->disparities < 1 || p->disparities > MOD_SGM_MAX_DISPARITIES) return fail(c, MOD_ERR_INVALID_ARGUMENT, "disparities must be in 1..128");
+  if (p->p1 < 0 || p->p2 < p->p1 || 31 + p->p2 > 255) return fail(c, MOD_ERR_INVALID_ARGUMENT, "need 0 <= P1 <= P2 <= 224 (path costs are uint8)");
+  if (direction != 0 && direction != 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "only the horizontal paths (0: left to right, 1: right to left) exist so far");
+  if ((size_t)c->dc.W * 8 > 64 * 1024) return fail(c, MOD_ERR_CAPACITY, "image row does not fit the census row buffer in LDS");
+  launch_sgm_path_h(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction == 1, census_left, census_right, path_cost,
+                    matching_cost, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
 // ---- host-pointer convenience --------------------------------------------------------------------------------------
 static int ensure_host_staging(ModContext *c) {
   Buffers &b = c->b;
