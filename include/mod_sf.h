@@ -173,24 +173,33 @@ int  mod_process_dev(ModContext *ctx, const ModFrameBatch *in, const ModSceneFlo
 int  mod_pack_cloud_dev(ModContext *ctx, int32_t frames, const ModSceneFlowPlanes *planes, void *cloud_aos);
 int  mod_unpack_cloud_dev(ModContext *ctx, int32_t frames, const void *cloud_aos, const ModSceneFlowPlanes *planes);
 
-/* ---- on-GPU disparity: FIRST STAGES, the estimator is not complete yet ------------------------------ */
+/* ---- on-GPU disparity (BASELINE config 5) ------------------------------------------------------------ */
 /* The reference obtains disparity_now from sgm_gpu::SgmGpu::computeDisparity(left, right, left_info, right_info, disparity)
- * (scene_flow_constructor/src/scene_flow_constructor.cpp:35,267; package sgm_gpu of sgm_gpu_ros, not vendored).  Algorithm and
- * parameters: oracle/sgm_ref.cpp.  Available so far: the census transform and the two horizontal aggregation paths; the remaining
- * six paths, winner-take-all, median and the left-right check follow.  Planes are [frames][H][W] of the
- * configured camera size; cost volumes are [frames][H][W][disparities] uint8. */
+ * (scene_flow_constructor/src/scene_flow_constructor.cpp:35,267; package sgm_gpu of sgm_gpu_ros, not vendored).  Algorithm,
+ * parameters and every choice the publication leaves open: oracle/sgm_ref.cpp (semi-global matching: centre-symmetric 9 x 7
+ * census, Hamming cost, 8 paths with P1 / P2, winner-take-all, 3 x 3 median, left-right check).  Images are 8-bit, rectified,
+ * [frames][H][W] of the configured camera size; the result is the `image` of a stereo_msgs/DisparityImage (32FC1, invalid
+ * pixels -1 = min_disparity - 1) whose other fields are f, T of the camera, min_disparity 0, max_disparity disparities - 1 —
+ * exactly what mod_set_camera takes as disp_f, disp_T, min_disparity, max_disparity
+ * (disparity_image_proc/src/disparity_image_processor.cpp:25-27,41-42). */
 #define MOD_SGM_MAX_DISPARITIES 128
 typedef struct ModSgmParams {
   int32_t disparities;   /* D <= 128; default 128 */
   int32_t p1, p2;        /* smoothness penalties; defaults 6, 96; 31 + p2 must fit uint8 */
-  int32_t paths;         /* 8 (or 4) — recorded for the complete estimator */
+  int32_t paths;         /* 8, or 4 (the horizontal and vertical ones) */
   int32_t lr_check;      /* left-right consistency check, tolerance 1 */
-  int32_t median;        /* 3 x 3 median of the winner-take-all map */
+  int32_t median;        /* 3 x 3 median of the winner-take-all maps */
 } ModSgmParams;
-/* centre-symmetric 9 x 7 census of 8-bit images, 31 bits per pixel (0 where the window leaves the image) */
+/* computeDisparity: device images in, device disparity plane out (enqueued on the context's stream; scratch — one cost volume of
+ * W*H*disparities uint16 — is allocated on first use).  NULL image -> MOD_SKIP_NO_DISPARITY_NOW, as a failed estimateDisparity. */
+int  mod_sgm_compute_dev(ModContext *ctx, int32_t frames, const uint8_t *left, const uint8_t *right, const ModSgmParams *params,
+                         float *disparity);
+/* the same for one frame in host memory (what a ROS node holding sensor_msgs/Image buffers calls); synchronous */
+int  mod_sgm_compute_host(ModContext *ctx, const uint8_t *left, const uint8_t *right, const ModSgmParams *params, float *disparity);
+/* stages, for tests and tracing: centre-symmetric census (31 bits per pixel, 0 where the window leaves the image) ... */
 int  mod_sgm_census_dev(ModContext *ctx, int32_t frames, const uint8_t *image, uint32_t *census);
-/* one aggregation path L_r over the Hamming cost of the census words; direction 0 = left to right, 1 = right to left (others:
- * MOD_ERR_INVALID_ARGUMENT for now).  matching_cost (optional) receives C itself. */
+/* ... and one aggregation path L_r [frames][H][W][disparities] uint8 over the Hamming cost of the census words; direction 0..7 =
+ * (+1,0) (-1,0) (0,+1) (0,-1) (+1,+1) (-1,-1) (-1,+1) (+1,-1).  matching_cost (optional) receives C itself. */
 int  mod_sgm_path_dev(ModContext *ctx, int32_t frames, const uint32_t *census_left, const uint32_t *census_right,
                       const ModSgmParams *params, int32_t direction, uint8_t *path_cost, uint8_t *matching_cost);
 

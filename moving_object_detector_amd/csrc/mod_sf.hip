@@ -41,6 +41,11 @@ struct Buffers {
   void *h_aos = nullptr;
   int32_t *h_labels = nullptr, *h_nobj = nullptr;
   ModObject *h_objects = nullptr;
+  // on-GPU disparity (allocated on first use)
+  uint32_t *sgm_census = nullptr;
+  uint8_t *sgm_maps = nullptr;
+  uint16_t *sgm_S = nullptr;
+  int sgm_D = 0;
 };
 
 }  // namespace
@@ -360,7 +365,7 @@ void mod_destroy(ModContext *c) {
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
   void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.rsize, b.rkey, b.cbox, b.counters, b.clusters, b.mbits, b.mpix,
-                 b.cursors, b.worklist, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects};
+                 b.cursors, b.worklist, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects, b.sgm_census, b.sgm_maps, b.sgm_S};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
     if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
@@ -528,22 +533,88 @@ int mod_sgm_census_dev(ModContext *c, int32_t frames, const uint8_t *image, uint
   return MOD_OK;
 }
 
+static int check_sgm_params(ModContext *c, const ModSgmParams *p) {
+  if (!p) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null SGM parameters");
+  if (p->disparities < 1 || p->disparities > MOD_SGM_MAX_DISPARITIES) return fail(c, MOD_ERR_INVALID_ARGUMENT, "disparities must be in 1..128");
+  if (p->p1 < 0 || p->p2 < p->p1 || 31 + p->p2 > 255) return fail(c, MOD_ERR_INVALID_ARGUMENT, "need 0 <= P1 <= P2 <= 224 (path costs are uint8)");
+  if (p->paths != 4 && p->paths != 8) return fail(c, MOD_ERR_INVALID_ARGUMENT, "paths must be 4 or 8");
+  if ((size_t)c->dc.W * 8 > 64 * 1024) return fail(c, MOD_ERR_CAPACITY, "image row does not fit the census row buffer in LDS");
+  return MOD_OK;
+}
+
 int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left, const uint32_t *census_right, const ModSgmParams *p,
                      int32_t direction, uint8_t *path_cost, uint8_t *matching_cost) {
   int rc = check_ready(c, frames);
   if (rc) return rc;
-  if (!census_left || !census_right || !p || !path_cost) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null plane / parameters");
-  if (p->disparities < 1 || p->disparities > MOD_SGM_MAX_DISPARITIES) return fail(c, MOD_ERR_INVALID_ARGUMENT, "disparities must be in 1..128");
-  if (p->p1 < 0 || p->p2 < p->p1 || 31 + p->p2 > 255) return fail(c, MOD_ERR_INVALID_ARGUMENT, "need 0 <= P1 <= P2 <= 224 (path costs are uint8)");
-  if (direction != 0 && direction != 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "only the horizontal paths (0: left to right, 1: right to left) exist so far");
-  if ((size_t)c->dc.W * 8 > 64 * 1024) return fail(c, MOD_ERR_CAPACITY, "image row does not fit the census row buffer in LDS");
-  launch_sgm_path_h(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction == 1, census_left, census_right, path_cost,
-                    matching_cost, c->stream);
+  if (!census_left || !census_right || !path_cost) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null plane");
+  if ((rc = check_sgm_params(c, p))) return rc;
+  if (direction < 0 || direction > 7) return fail(c, MOD_ERR_INVALID_ARGUMENT, "direction must be 0..7");
+  launch_sgm_path(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction, census_left, census_right, path_cost,
+                  matching_cost, nullptr, false, c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+// scratch of the complete estimator, for ONE frame (frames of a batch are processed one after the other on the stream):
+// two census planes, the summed cost volume (uint16), four disparity maps
+static int ensure_sgm_scratch(ModContext *c, int D) {
+  Buffers &b = c->b;
+  const size_t N = c->maxN;
+  if (b.sgm_S && b.sgm_D >= D) return MOD_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (b.sgm_S) { HIP_TRY(c, hipFree(b.sgm_S)); b.sgm_S = nullptr; }
+  b.sgm_D = 0;
+  HIP_TRY(c, dalloc(&b.sgm_census, 2 * N));
+  HIP_TRY(c, dalloc(&b.sgm_maps, 4 * N));
+  HIP_TRY(c, dalloc(&b.sgm_S, N * (size_t)D));
+  b.sgm_D = D;
+  return MOD_OK;
+}
+
+int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, const uint8_t *right, const ModSgmParams *p, float *disparity) {
+  int rc = check_ready(c, frames);
+  if (rc) return rc;
+  if (!left || !right) return MOD_SKIP_NO_DISPARITY_NOW;     // no image pair: no disparity (estimateDisparity fails, :272-276)
+  if (!disparity) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null disparity plane");
+  if ((rc = check_sgm_params(c, p))) return rc;
+  if ((rc = ensure_sgm_scratch(c, p->disparities))) return rc;
+  const int W = c->dc.W, H = c->dc.H, D = p->disparities;
+  const size_t N = (size_t)W * H;
+  Buffers &b = c->b;
+  uint32_t *cl = b.sgm_census, *cr = b.sgm_census + N;
+  uint8_t *dl = b.sgm_maps, *dr = dl + N, *dlm = dr + N, *drm = dlm + N;
+  static const int order4[4] = {0, 1, 2, 3};
+  for (int f = 0; f < frames; f++) {
+    launch_sgm_census(W, H, 1, left + (size_t)f * N, cl, c->stream);
+    launch_sgm_census(W, H, 1, right + (size_t)f * N, cr, c->stream);
+    for (int i = 0; i < p->paths; i++)
+      launch_sgm_path(W, H, 1, D, p->p1, p->p2, p->paths == 4 ? order4[i] : i, cl, cr, nullptr, nullptr, b.sgm_S, i == 0, c->stream);
+    launch_sgm_finish(W, H, D, p->median, p->lr_check, b.sgm_S, dl, dr, dlm, drm, disparity + (size_t)f * N, c->stream);
+  }
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;
 }
 
 // ---- host-pointer convenience --------------------------------------------------------------------------------------
+static int ensure_host_staging(ModContext *c);
+
+int mod_sgm_compute_host(ModContext *c, const uint8_t *left, const uint8_t *right, const ModSgmParams *p, float *disparity) {
+  int rc = check_ready(c, 1);
+  if (rc) return rc;
+  if (!left || !right) return MOD_SKIP_NO_DISPARITY_NOW;
+  if (!disparity) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null disparity image");
+  if ((rc = ensure_host_staging(c))) return rc;
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  Buffers &b = c->b;
+  uint8_t *dimg = reinterpret_cast<uint8_t *>(b.h_flow);          // staging: the 8 N bytes of the flow slot hold both images
+  HIP_TRY(c, hipMemcpyAsync(dimg, left, N, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(dimg + N, right, N, hipMemcpyHostToDevice, c->stream));
+  if ((rc = mod_sgm_compute_dev(c, 1, dimg, dimg + N, p, b.h_dnow))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(disparity, b.h_dnow, 4 * N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MOD_OK;
+}
+
 static int ensure_host_staging(ModContext *c) {
   Buffers &b = c->b;
   if (b.h_objects) return MOD_OK;                    // the last buffer of the set exists: all do

@@ -31,7 +31,7 @@ def _stages(ctx, left, right, D, P1=6, P2=96):
     assert ctx.lib.mod_sgm_census_dev(ctx.h, F, dr.data_ptr(), cr.data_ptr()) == 0
     prm = capi.ModSgmParams(D, P1, P2, 8, 1, 1)
     out = {}
-    for direction in (0, 1):
+    for direction in range(8):
         L = torch.full((F, H, W, D), 255, dtype=torch.uint8, device=dev)
         Cv = torch.full((F, H, W, D), 255, dtype=torch.uint8, device=dev)
         assert ctx.lib.mod_sgm_path_dev(ctx.h, F, cl.data_ptr(), cr.data_ptr(), C.byref(prm), direction, L.data_ptr(), Cv.data_ptr()) == 0
@@ -41,7 +41,7 @@ def _stages(ctx, left, right, D, P1=6, P2=96):
 
 
 @pytest.mark.parametrize("W,H,D,F,seed", [(320, 240, 128, 1, 1), (131, 77, 64, 2, 2), (70, 9, 128, 1, 3), (257, 33, 100, 3, 4), (9, 7, 8, 1, 5)])
-def test_census_and_horizontal_paths_match_the_oracle(W, H, D, F, seed):
+def test_census_and_all_eight_paths_match_the_oracle(W, H, D, F, seed):
     from oracle import pysgm
     from oracle import sgm_numpy as sn
     pairs = [sn.make_stereo(W, H, seed * 10 + f, D, n_boxes=3) for f in range(F)]
@@ -51,7 +51,7 @@ def test_census_and_horizontal_paths_match_the_oracle(W, H, D, F, seed):
     for f in range(F):
         assert np.array_equal(cl[f], pysgm.census(left[f])) and np.array_equal(cr[f], pysgm.census(right[f]))
         Cref = pysgm.cost(cl[f], cr[f], D)
-        for direction in (0, 1):
+        for direction in range(8):
             L, Cv = out[direction]
             assert np.array_equal(Cv[f], Cref), (f, direction)
             assert np.array_equal(L[f], pysgm.aggregate(Cref, 6, 96, direction)), (f, direction)
@@ -78,11 +78,96 @@ def test_fixture_and_argument_checks():
     assert ctx.lib.mod_sgm_path_dev(ctx.h, 1, tl.data_ptr(), tr.data_ptr(), C.byref(prm), 0, L.data_ptr(), None) == 0
     ctx.synchronize()
     assert np.array_equal(L.cpu().numpy()[0], pysgm.aggregate(pysgm.cost(cl[0], cr[0], 64), 3, 40, 0))
-    # what does not exist yet, and what cannot work, is an error — never a silent no-op
-    for bad_dir in (2, 7, -1):
+    # what cannot work is an error — never a silent no-op
+    for bad_dir in (8, -1):
         assert ctx.lib.mod_sgm_path_dev(ctx.h, 1, tl.data_ptr(), tr.data_ptr(), C.byref(prm), bad_dir, L.data_ptr(), None) == capi.MOD_ERR_INVALID_ARGUMENT
-    assert b"horizontal" in ctx.lib.mod_last_error(ctx.h)
-    for bad in (capi.ModSgmParams(0, 6, 96, 8, 1, 1), capi.ModSgmParams(129, 6, 96, 8, 1, 1), capi.ModSgmParams(64, 6, 230, 8, 1, 1), capi.ModSgmParams(64, 50, 40, 8, 1, 1)):
+    assert b"direction" in ctx.lib.mod_last_error(ctx.h)
+    for bad in (capi.ModSgmParams(0, 6, 96, 8, 1, 1), capi.ModSgmParams(129, 6, 96, 8, 1, 1), capi.ModSgmParams(64, 6, 230, 8, 1, 1), capi.ModSgmParams(64, 50, 40, 8, 1, 1),
+                capi.ModSgmParams(64, 6, 96, 5, 1, 1)):
         assert ctx.lib.mod_sgm_path_dev(ctx.h, 1, tl.data_ptr(), tr.data_ptr(), C.byref(bad), 0, L.data_ptr(), None) == capi.MOD_ERR_INVALID_ARGUMENT
     assert ctx.lib.mod_sgm_census_dev(ctx.h, 1, None, tl.data_ptr()) == capi.MOD_ERR_INVALID_ARGUMENT
+    ctx.close()
+
+
+def _compute(ctx, left, right, **kw):
+    from moving_object_detector_amd import capi
+    F, H, W = left.shape
+    dev = ctx.device
+    prm = capi.ModSgmParams(kw.get("D", 128), kw.get("P1", 6), kw.get("P2", 96), kw.get("paths", 8), int(kw.get("lr_check", True)),
+                            int(kw.get("median", True)))
+    out = torch.full((F, H, W), -7.0, dtype=torch.float32, device=dev)
+    tl, tr = torch.from_numpy(left).to(dev), torch.from_numpy(right).to(dev)       # kept alive until the kernels have run
+    rc = ctx.lib.mod_sgm_compute_dev(ctx.h, F, tl.data_ptr(), tr.data_ptr(), C.byref(prm), out.data_ptr())
+    assert rc == 0, ctx.lib.mod_last_error(ctx.h)
+    ctx.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("W,H,D,F,seed", [(320, 240, 128, 2, 1), (131, 77, 64, 1, 2), (70, 9, 128, 1, 3), (9, 7, 8, 1, 5)])
+def test_complete_estimator_matches_the_oracle(W, H, D, F, seed):
+    from oracle import pysgm
+    from oracle import sgm_numpy as sn
+    pairs = [sn.make_stereo(W, H, seed * 10 + f, D, n_boxes=3) for f in range(F)]
+    left, right = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+    ctx = _ctx(W, H, F)
+    for kw in (dict(), dict(paths=4), dict(lr_check=False, median=False), dict(P1=3, P2=40, median=False)):
+        got = _compute(ctx, left, right, D=D, **kw)
+        for f in range(F):
+            want = pysgm.compute(left[f], right[f], D, kw.get("P1", 6), kw.get("P2", 96), kw.get("paths", 8), kw.get("lr_check", True),
+                                 kw.get("median", True))
+            assert np.array_equal(got[f], want), (kw, f, int((got[f] != want).sum()))
+    g = np.load(GOLD)
+    if (W, H, D) == (320, 240, 128):
+        assert np.array_equal(_compute(ctx, g["left"][None], g["right"][None])[0], g["disparity"])
+        # the host-pointer form
+        from moving_object_detector_amd import capi
+        gl, gr = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
+        host = np.full((H, W), -7.0, np.float32)
+        prm = capi.ModSgmParams(128, 6, 96, 8, 1, 1)
+        assert ctx.lib.mod_sgm_compute_host(ctx.h, gl.ctypes.data, gr.ctypes.data, C.byref(prm), host.ctypes.data) == 0
+        assert np.array_equal(host, g["disparity"])
+        assert ctx.lib.mod_sgm_compute_host(ctx.h, None, gr.ctypes.data, C.byref(prm), host.ctypes.data) == capi.MOD_SKIP_NO_DISPARITY_NOW
+    ctx.close()
+
+
+def test_config5_images_to_moving_objects(oracle):
+    """BASELINE config 5's data path at its stated size: 1920 x 1080 stereo images -> on-GPU SGM disparity (now and previous) ->
+    scene flow + clustering, every stage against its CPU restatement.  The disparity planes never leave the GPU."""
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import PLANES, Context
+    from oracle import pysgm
+    from oracle import sgm_numpy as sn
+    from util import bits_equal
+    W, H, D = 1920, 1080, 128
+    l0, r0, _ = sn.make_stereo(W, H, 41, D, n_boxes=5)
+    l1, r1, _ = sn.make_stereo(W, H, 42, D, n_boxes=5)
+    cam = synth.make_camera(W, H)
+    cam.min_disparity, cam.max_disparity = np.float32(0.0), np.float32(D - 1)      # the DisparityImage fields of this estimator
+    prm = synth.Params()
+    ctx = Context(W, H, max_frames=2)
+    ctx.set_camera(cam)
+    ctx.set_params(prm)
+    dev = ctx.device
+    sp = capi.ModSgmParams(D, 6, 96, 8, 1, 1)
+    imgs_l, imgs_r = torch.from_numpy(np.stack([l0, l1])).to(dev), torch.from_numpy(np.stack([r0, r1])).to(dev)
+    disp = torch.empty((2, H, W), dtype=torch.float32, device=dev)                 # [0] = previous, [1] = now
+    assert ctx.lib.mod_sgm_compute_dev(ctx.h, 2, imgs_l.data_ptr(), imgs_r.data_ptr(), C.byref(sp), disp.data_ptr()) == 0
+    ctx.synchronize()
+    want = [pysgm.compute(l0, r0, D), pysgm.compute(l1, r1, D)]
+    got = disp.cpu().numpy()
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert (got >= 0).mean() > 0.6
+    # scene flow + clusters from the device-resident disparities
+    rng = np.random.default_rng(5)
+    flow = rng.uniform(-3, 3, size=(1, H, W, 2)).astype(np.float32)
+    t, q = np.array([[0.01, 0.0, 0.08]]), np.array([[0.0, 0.003, 0.0, 1.0]])
+    ws = ctx.workspace(1)
+    b = ctx.make_batch(disp[1:2], disp[0:1], torch.from_numpy(flow).to(dev), t, q, [0.1])
+    assert ctx.process(b, ws) == 0
+    ctx.synchronize()
+    ref = oracle.construct(cam, prm, want[1], want[0], flow[0], t[0], q[0], 0.1, "tidy")
+    for i, k in enumerate(PLANES):
+        assert bits_equal(ws["planes"][i, 0].cpu().numpy(), ref[k]), k
+    labels, objs, K = oracle.cluster(ref, prm, "tidy")
+    assert np.array_equal(ws["labels"][0].cpu().numpy(), labels) and int(ws["n_objects"][0]) == len(objs)
     ctx.close()
