@@ -10,12 +10,14 @@
 
 namespace scene_flow_clusterer {
 
+#ifndef MOD_HOST_ROS_CONFIG   // a ROS build includes the dynamic_reconfigure-generated scene_flow_clusterer/ClustererConfig.h first
 struct ClustererConfig {   // cfg/Clusterer.cfg:8-11
   int cluster_size = 2500;
   double depth_diff = 0.15;
   double dynamic_speed = 0.3;
   int neighbor_distance = 4;
 };
+#endif
 
 class ClustererNodelet {
  public:

@@ -1,5 +1,6 @@
 // clusterer_nodelet_ros.cpp — ROS-1 nodelet shell around scene_flow_clusterer::ClustererNodelet (host mirror).
-// NOT BUILT HERE (no ROS in this image): field mapping only.  Plugin identity as in the reference:
+// Not built in this image (no ROS); tests/test_ros_adapter_syntax.py keeps it compiling against declaration-only stand-ins of
+// the ROS types.  Field mapping only.  Plugin identity as in the reference (nodelet_plugins.xml beside this file):
 // PLUGINLIB_EXPORT_CLASS(scene_flow_clusterer::ClustererNodeletRos, nodelet::Nodelet) with the class name
 // "scene_flow_clusterer/scene_flow_clusterer" in nodelet_plugins.xml.
 #include <dynamic_reconfigure/server.h>
@@ -10,6 +11,7 @@
 #include <scene_flow_clusterer/ClustererConfig.h>
 #include <sensor_msgs/PointCloud2.h>
 
+#define MOD_HOST_ROS_CONFIG   // ClustererConfig is the generated one
 #include "../clusterer_nodelet.hpp"
 
 namespace scene_flow_clusterer {
@@ -25,7 +27,7 @@ class ClustererNodeletRos : public nodelet::Nodelet {
     impl_.reset(new ClustererNodelet(ctx_));
     server_.reset(new dynamic_reconfigure::Server<scene_flow_clusterer::ClustererConfig>(pnh));
     server_->setCallback([this](scene_flow_clusterer::ClustererConfig &c, uint32_t) {
-      impl_->reconfigureCB({c.cluster_size, c.depth_diff, c.dynamic_speed, c.neighbor_distance});
+      impl_->reconfigureCB(c);
     });
     pub_ = pnh.advertise<moving_object_msgs::MovingObjectArray>("moving_objects", 1);
     sub_ = nh.subscribe<sensor_msgs::PointCloud2>("scene_flow", 10, &ClustererNodeletRos::dataCB, this);

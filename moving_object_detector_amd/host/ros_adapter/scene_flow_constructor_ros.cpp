@@ -1,7 +1,10 @@
 // scene_flow_constructor_ros.cpp — ROS-1 node shell around scene_flow_constructor::SceneFlowConstructor (host mirror).
-// NOT BUILT HERE (no ROS / sgm_gpu / pwc_net / viso2 in this image): shows where the three estimators hand their
+// Not built in this image (no ROS / pwc_net / viso2); tests/test_ros_adapter_syntax.py keeps it compiling against declaration-only
+// stand-ins of the ROS types.  Shows where the three estimators hand their
 // outputs to construct() (scene_flow_constructor.cpp:378-392) and how the results map back onto the reference's topics.
+#include <geometry_msgs/Transform.h>
 #include <ros/ros.h>
+#include <sensor_msgs/Image.h>
 #include <sensor_msgs/PointCloud2.h>
 #include <stereo_msgs/DisparityImage.h>
 
