@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       const int rgr = r / PW, rgc = r - rgr * PW;
       rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
       rc = r;
-      a.parent[fN + (size_t)gy * c.W + x0 + lane] = rg;
+      if (MOD_CHECK(a, rg >= 0 && (size_t)rg < N && rgr >= NMAX && rgc >= NMAX, 13)) a.parent[fN + (size_t)gy * c.W + x0 + lane] = rg;
       isroot = (r == me);
     }
     rootg[j] = rg; rootc[j] = rc;
@@ -413,7 +413,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_nreq, __popcll((unsigned long long)lb));
         base = __shfl(base, 0);
-        if (linked) req[base + __popcll((unsigned long long)(lb & ((1ull << lane) - 1ull)))] = make_uint2((uint32_t)hg, (uint32_t)rg);
+        if (linked) {
+          const int slot = base + __popcll((unsigned long long)(lb & ((1ull << lane) - 1ull)));
+          if (MOD_CHECK(a, slot >= 0 && slot < a.req_cap, 12) && MOD_CHECK(a, rg >= 0 && (size_t)rg < N && hg >= 0 && (size_t)hg < N, 13))
+            req[slot] = make_uint2((uint32_t)hg, (uint32_t)rg);
+        }
       }
     }
   }
@@ -494,7 +498,8 @@ __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_
     int ra = -1, rb = -1;
     if (i0 + tid < total) {
       const uint2 q = a.requests[((size_t)f * tiles_per_frame + t0 + u) * a.req_cap + i];
-      ra = parent[q.x]; rb = (int)q.y;
+      if (MOD_CHECK(a, (size_t)q.x < N && (size_t)q.y < N, 0)) { ra = parent[q.x]; rb = (int)q.y; }
+      if (!MOD_CHECK(a, ra < 0 || ((size_t)ra < N && rb >= 0), 1)) ra = -1;
     }
     const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
     if (ra >= 0 && !(lane > 0 && pa == ra && pb == rb)) uf_unite(parent, ra, rb);
@@ -523,9 +528,10 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
     bits &= bits - 1ull;
     const int p = y * c.W + wi * 64 + b;
     const int r = uf_find(parent, p);
+    if (!MOD_CHECK(a, r >= 0 && (size_t)r < N, 2)) continue;
     if (r == p) {
       const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
-      a.rootlist[(size_t)f * N + slot] = p;
+      if (MOD_CHECK(a, slot >= 0 && (size_t)slot < N, 3)) a.rootlist[(size_t)f * N + slot] = p;
     } else {
       parent[p] = r;   // r is final: no union runs after k_ccl_link
       const int sz = rsize[p], ky = rkey[p];
@@ -552,6 +558,7 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
   // a component without any edge never got a label in the reference (key == none)
   for (int i = tid; i < nroots; i += 256) {
     const int r = roots[i];
+    if (!MOD_CHECK(a, r >= 0 && (size_t)r < N, 4)) continue;
     const int size = rsize[r], key = rkey[r];
     bool keep = (key != kKeyNone) && (size >= c.cluster_size);
     if (keep) {
@@ -635,7 +642,7 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   for (int j = 0; j < RPW; j++) {
     if ((rw[j] >> lane) & 1ull) {
       const int cell = (r0 + j) * 64 + lane;
-      nlmap[cell] = a.rkey[fN + par[j]];
+      nlmap[cell] = MOD_CHECK(a, par[j] >= 0 && (size_t)par[j] < N, 5) ? a.rkey[fN + par[j]] : -1;
       lcount[cell] = 0;
     }
   }
@@ -654,8 +661,10 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
     const int ly = (int)(((float)d + 0.5f) * invW);
     // a tile root's own entry was redirected to the final root (possibly in another tile) by k_ccl_merge: it is its own cell
     const bool isroot = (rw[j] >> lane) & 1ull;
-    const int cl = !dyn ? 0 : isroot ? ((r0 + j) * 64 + lane) : (ly * 64 + (d - ly * c.W));
-    const int l = dyn ? nlmap[cl] : -1;
+    int cl = !dyn ? 0 : isroot ? ((r0 + j) * 64 + lane) : (ly * 64 + (d - ly * c.W));
+    if (!MOD_CHECK(a, cl >= 0 && cl < TH * 64 && (!dyn || isroot || (d >= 0 && d - ly * c.W < 64)), 6)) cl = 0;
+    int l = dyn ? nlmap[cl] : -1;
+    if (!MOD_CHECK(a, l >= -1 && l < a.max_objects, 7)) l = -1;
     nl[j] = l; cell[j] = cl; rank[j] = 0;
     if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = l;
     any_member = any_member || (__ballot(l >= 0) != 0);
@@ -706,8 +715,10 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
     for (int j = 0; j < RPW; j++) {
       if (nl[j] >= 0) {
         const size_t slot = fN + lcount[cell[j]] + rank[j];
-        a.mbits[slot] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
-        a.mpix[slot] = (uint32_t)((y0 + r0 + j) * c.W + x);
+        if (MOD_CHECK(a, lcount[cell[j]] >= 0 && rank[j] >= 0 && (size_t)(lcount[cell[j]] + rank[j]) < N, 8)) {
+          a.mbits[slot] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
+          a.mpix[slot] = (uint32_t)((y0 + r0 + j) * c.W + x);
+        }
       }
     }
     // bounding box of the cluster (pcl::getMinMax3D in cluster2MovingObject, clusterer_nodelet.cpp:151-152): the wave's members
@@ -785,7 +796,8 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     const uint32_t item = a.worklist[wi];
     const int f = (int)(item / (uint32_t)a.max_objects), k = (int)(item % (uint32_t)a.max_objects);
     ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
-    const int size = ci->size;
+    const int size = MOD_CHECK(a, ci->size >= 1 && ci->offset >= 0 && (size_t)ci->offset + (size_t)ci->size <= N, 9) ? ci->size : 0;
+    if (size == 0) continue;                                        // (checked build only; block-uniform)
     const uint32_t *sbits = a.mbits + (size_t)f * N + ci->offset;   // ||v|| bits of the members ...
     const uint32_t *spix = a.mpix + (size_t)f * N + ci->offset;     // ... and their pixel indices
     const ClusterBox rec = a.cbox[(size_t)f * a.max_objects + k];   // complete: k_final has finished; in flight meanwhile
@@ -905,6 +917,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     __syncthreads();
     uint32_t best = (uint32_t)(s_best & 0xffffffffull);
     if (s_best == ~0ull) best = spix[0];            // unreachable for consistent input; keeps every access in bounds
+    if (!MOD_CHECK(a, s_best != ~0ull && (size_t)best < N, 10)) best = 0;
     const float bvx = a.vx[(size_t)f * N + best], bvy = a.vy[(size_t)f * N + best], bvz = a.vz[(size_t)f * N + best];
     if (nties > 1u) {                                // block-uniform: a single member of that norm cannot tie
       auto differs = [&](uint32_t p) {
@@ -1209,8 +1222,10 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
             int bit;
             const int cl = cell_of(p8[u], bit);
             const int slot = (int)cstart[cl] + __popcll((unsigned long long)(cmask[cl] & ((1ull << bit) - 1ull)));
-            key[slot] = k8[u];                        // ||v|| bits as k_final computed them (norm3_f32)
-            val[slot] = p8[u];
+            if (MOD_CHECK(a, cl >= 0 && cl < ncell && slot >= 0 && slot < size, 11)) {
+              key[slot] = k8[u];                      // ||v|| bits as k_final computed them (norm3_f32)
+              val[slot] = p8[u];
+            }
           }
       }
       __syncthreads();

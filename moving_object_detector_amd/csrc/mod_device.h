@@ -15,6 +15,18 @@
 #define MOD_ABLATE(c, bits) false
 #endif
 
+// Index assertions of the diagnostic build `make CHECKED=1` (libmod_sf_checked.so, tests/test_gpu_checked_build.py): every index
+// the cluster kernels derive from DATA IN MEMORY (parent entries, link requests, member slots, cluster tables) is checked
+// before it is used; a violation is counted in ClArgs.dbg[48 + code] and the access is skipped instead of faulting the GPU.
+// A product build compiles the conditions away.  Codes: 0 link request pixel, 1 link roots, 2 merge root, 3 root list slot,
+// 4 select root, 5 final: parent entry, 6 final: tile-root cell, 7 final: label, 8 final: member slot, 9 median: segment,
+// 10 median: member pixel, 11 ties: member slot, 12 tile: request slot, 13 tile: root pixel.
+#ifdef MOD_CHECKED
+#define MOD_CHECK(a, cond, code) ((cond) ? true : (atomicAdd(&(a).dbg[48 + (code)], 1ull), false))
+#else
+#define MOD_CHECK(a, cond, code) true
+#endif
+
 // Camera / parameter block as the kernels see it.  Everything that the reference computes per pixel but that only
 // depends on the camera (F32 product f*T, pixel rays, threshold conversions) is computed ONCE on the host with the same
 // IEEE operations and uploaded, so the per-pixel results stay bit-identical to the reference expressions.

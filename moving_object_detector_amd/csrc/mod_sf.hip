@@ -862,7 +862,7 @@ int mod_memcpy_d2h(ModContext *c, void *h, const void *d, uint64_t bytes) {
   return MOD_OK;
 }
 
-#if defined(MOD_PHASE_COUNTERS) || defined(MOD_ABLATION)
+#if defined(MOD_PHASE_COUNTERS) || defined(MOD_ABLATION) || defined(MOD_CHECKED)
 // diagnostic builds only (declared in mod_sf_debug.h; a product build does not export them)
 // copy an internal buffer to the host (0 members, 1 clusters, 2 counters, 3 cursors)
 int mod_debug_read(ModContext *c, int which, void *dst, unsigned long long bytes) {
