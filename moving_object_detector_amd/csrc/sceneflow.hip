@@ -190,25 +190,6 @@ template <class T> __device__ __forceinline__ T ld(const void *base, uint32_t by
 template <class T> __device__ __forceinline__ void st(void *base, uint32_t byte_off, const T &v) {
   *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
-// streaming forms (read once / written once): experiment switches SF_NT_LOAD / SF_NT_STORE
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_stream4(const void *base, uint32_t byte_off) {
-#ifdef SF_NT_LOAD
-  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(reinterpret_cast<const char *>(base) + byte_off));
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
-  return ld<float4>(base, byte_off);
-#endif
-}
-__device__ __forceinline__ void st_stream4(void *base, uint32_t byte_off, const float4 &v) {
-#ifdef SF_NT_STORE
-  f4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
-  __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(reinterpret_cast<char *>(base) + byte_off));
-#else
-  st(base, byte_off, v);
-#endif
-}
-
 // Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
 __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const int lane = threadIdx.x;                      // 0..63
@@ -237,10 +218,10 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   uint32_t nib = 0;
   if (inb) {
     const float *dprev_f = a.dprev + fN;
-    const float4 dn = ld_stream4(a.dnow + fN, o4);
+    const float4 dn = ld<float4>(a.dnow + fN, o4);
     const float4 dp = ld<float4>(dprev_f, o4);
-    const float4 fa = ld_stream4(a.flow + 2 * fN, o8);
-    const float4 fb = ld_stream4(a.flow + 2 * fN, o8 + 16u);
+    const float4 fa = ld<float4>(a.flow + 2 * fN, o8);
+    const float4 fb = ld<float4>(a.flow + 2 * fN, o8 + 16u);
     const double ry = c.rayy[y];
     const double2 rxa = ld<double2>(c.rayx, (uint32_t)x0 * 8u);
     const double2 rxb = ld<double2>(c.rayx, (uint32_t)x0 * 8u + 16u);
@@ -251,9 +232,9 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     sf_stage1(c, fc, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2, s2);
     sf_stage1(c, fc, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3, s3);
     // x, y, z are final after stage 1: their stores leave before the gathers come back
-    st_stream4(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
-    st_stream4(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
-    st_stream4(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
+    st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
+    st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
+    st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
     // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets
     const uint32_t W = (uint32_t)c.W;
     const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
@@ -275,9 +256,9 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
       sf_stage2b(c, fc, s2, w2, p2);
       sf_stage2b(c, fc, s3, w3, p3);
     }
-    st_stream4(a.vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
-    st_stream4(a.vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
-    st_stream4(a.vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
+    st(a.vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
+    st(a.vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
+    st(a.vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
     if (a.aos) {   // pcl::PointXYZVelocity records, 32 B each (pads written as 0)
       float4 *q = a.aos + 2 * fN;
       const uint32_t o32 = pix * 32u;
