@@ -145,6 +145,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __shared__ float zt[G];
   __shared__ int Lt[G];
   __shared__ uint64_t m0[PH], mL[PH];
+  __shared__ int s_uni[PH];                         // the one label every dynamic cell of the grid row carries after phase A3, or -1
   constexpr int kSlots = 32;
   __shared__ int s_any, s_nreq, s_nslots;
   __shared__ RootRec srec[kSlots];
@@ -220,50 +221,91 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   lds_barrier();
   STAMP(0)
   // ---- phase A1: horizontal runs of the wave's rows by ballot (no atomics) ---------------------------------------------
-  bool upr[RPW];
-#pragma unroll
-  for (int j = 0; j < RPW; j++) {
-    const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
-    const uint64_t mw = m0[rr + NMAX];
+  // One row of the grid: runs of the 64 tile columns by ballot; the left-halo cells chained to lane 0 by horizontal links
+  // (h0 - lane 0, h1 - h0, ...) join lane 0's run.  Returns "linked to the left neighbour" (an up-left edge).
+  auto link_row = [&](int gr) -> bool {
+    const bool halo_row = gr < NMAX;
+    const int me = gr * PW + NMAX + lane;
+    const uint64_t mw = m0[gr], ml = mL[gr];
     const bool dyn = (mw >> lane) & 1ull;
     const float z = zt[me];
     const float zl = __shfl_up(z, 1);
     const bool cl = dyn && lane > 0 && ((mw >> (lane - 1)) & 1ull) && !(fabsf(z - zl) > th);   // linked to the left neighbour
     const uint64_t C = __ballot(cl);
     const uint64_t starts = mw & ~C;                // run starts: dynamic and not linked to the left
+    // left-halo cells: lane j < n owns the cell in column x0-1-j; bit j of lk: it is linked to its right neighbour
+    const int hc = gr * PW + NMAX - 1 - min(lane, NMAX - 1);
+    const bool hdyn = lane < n && ((ml >> (63 - lane)) & 1ull);
+    const bool rdyn = lane == 0 ? (bool)(mw & 1ull) : (bool)((ml >> (64 - lane)) & 1ull);
+    const bool hl = hdyn && rdyn && !(fabsf(zt[hc] - zt[hc + 1]) > th);
+    const uint32_t lk = (uint32_t)__ballot(hl);
+    const int m = __builtin_ctz(~lk);               // cells h0 .. h(m-1) hang on lane 0 through an unbroken chain of links
+    // label of lane 0's run: its own cell — in a halo row the leftmost chained cell (parents must not be larger than children)
+    const int id0 = halo_row ? ((gr * PW + NMAX - m) | kHaloBit) : (gr * PW + NMAX);
     if (dyn) {
       const int s = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
-      Lt[me] = me - lane + s;
+      Lt[me] = s == 0 ? id0 : ((me - lane + s) | (halo_row ? kHaloBit : 0));
     }
-    upr[j] = cl;
+    if (lane < m) Lt[hc] = id0;
+    return cl || (lane == 0 && m > 0);
+  };
+  bool upr[RPW];
+#pragma unroll
+  for (int j = 0; j < RPW; j++) {
+    const int rr = w + NW * j;
+    upr[j] = link_row(rr + NMAX);
   }
+  for (int hr = NMAX - 1 - w; hr >= NMAX - n; hr -= NW)   // the halo rows above the tile, dealt to the waves like the tile rows
+    if (m0[hr] | mL[hr]) link_row(hr);                    // wave-uniform
   lds_barrier();
   // ---- phase A2: vertical pre-link (the pixel straight above), one union per distinct (run, run-above) pair -----------
-#pragma unroll
-  for (int j = 0; j < RPW; j++) {
-    const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
-    const uint64_t mw = m0[rr + NMAX], mu = m0[rr + NMAX - 1];
-    if ((mw & mu) == 0 || MOD_ABLATE(c, 2048)) continue;                    // wave-uniform
-    const bool v = ((mw & mu) >> lane) & 1ull;
-    const bool link = v && !(fabsf(zt[me] - zt[me - PW]) > th);
-    int cur = ld_relaxed(&Lt[me]), last = -1;
-    if (rr == 0) {                                   // wave-uniform: the row above is the halo, its cells are unhooked
-      if (link) atomicMin(&Lt[me - PW], cur);
-    } else {
+  auto link_up = [&](int gr) -> bool {              // grid row gr with grid row gr - 1 (tile rows and halo rows alike)
+    const int me = gr * PW + NMAX + lane;
+    const uint64_t both = m0[gr] & m0[gr - 1], hboth = (mL[gr] & mL[gr - 1]) >> (64 - NMAX);
+    bool link = false;
+    if (both != 0 && !MOD_ABLATE(c, 2048)) {                                // wave-uniform
+      link = ((both >> lane) & 1ull) && !(fabsf(zt[me] - zt[me - PW]) > th);
+      int cur = ld_relaxed(&Lt[me]), last = -1;
       wave_unite_lds(Lt, link, cur, last, ld_relaxed(&Lt[me - PW]), lane);
     }
-    upr[j] = upr[j] || link;
-  }
-  lds_barrier();
-  // ---- phase A3: flatten, so that phase B can compare labels directly -------------------------------------------------
+    if (hboth != 0) {                                                       // wave-uniform: the left-halo cells, column by column
+      const int hc = gr * PW + NMAX - 1 - min(lane, NMAX - 1);
+      const bool hlink = lane < n && ((hboth >> (NMAX - 1 - lane)) & 1ull) && !(fabsf(zt[hc] - zt[hc - PW]) > th);
+      int cur = ld_relaxed(&Lt[hc]), last = -1;
+      wave_unite_lds(Lt, hlink, cur, last, ld_relaxed(&Lt[hc - PW]), lane);
+    }
+    return link;
+  };
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
-    const int rr = w + NW * j, me = (rr + NMAX) * PW + NMAX + lane;
-    const uint64_t mw = m0[rr + NMAX];
-    const bool dyn = (mw >> lane) & 1ull;
-    int lab = -1;
-    if (dyn) { lab = lds_find(Lt, me); if (lab != me) Lt[me] = lab; }
+    const int rr = w + NW * j;
+    const bool link = link_up(rr + NMAX);
+    upr[j] = upr[j] || link;
   }
+  for (int hr = NMAX - 1 - w; hr > NMAX - n; hr -= NW) link_up(hr);
+  lds_barrier();
+  // ---- phase A3: flatten, so that phase B can compare labels directly -------------------------------------------------
+  auto flatten_row = [&](int gr) {
+    const int me = gr * PW + NMAX + lane;
+    const bool dyn = (m0[gr] >> lane) & 1ull, hdyn = lane < n && ((mL[gr] >> (63 - lane)) & 1ull);
+    int lab = -1, hlab = -1;
+    if (dyn) { lab = lds_find(Lt, ld_relaxed(&Lt[me])); if (ld_relaxed(&Lt[me]) != lab) Lt[me] = lab; }
+    if (hdyn) {
+      const int hc = gr * PW + NMAX - 1 - lane;
+      hlab = lds_find(Lt, ld_relaxed(&Lt[hc]));
+      if (ld_relaxed(&Lt[hc]) != hlab) Lt[hc] = hlab;
+    }
+    // row summary for phase B: when this row and a window row both carry one and the same label, no union can come of them
+    const uint64_t db = __ballot(dyn), hb = __ballot(hdyn);
+    int first = -1;
+    if (db) first = __builtin_amdgcn_readlane(lab, __builtin_ctzll(db));
+    else if (hb) first = __builtin_amdgcn_readlane(hlab, __builtin_ctzll(hb));
+    const bool uni = __ballot((dyn && lab != first) || (hdyn && hlab != first)) == 0;
+    if (lane == 0) s_uni[gr] = uni ? first : -1;
+  };
+#pragma unroll
+  for (int j = 0; j < RPW; j++) flatten_row(w + NW * j + NMAX);
+  for (int hr = NMAX - 1 - w; hr >= NMAX - n; hr -= NW) flatten_row(hr);
   lds_barrier();
   STAMP(1)
   // ---- phase B: the rest of the up-left window --------------------------------------------------------------------------
@@ -278,6 +320,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const float zp = zt[me];
     int cur = dyn ? ld_relaxed(&Lt[me]) : -1, last = -1;
     bool up = upr[j];
+    const int ul = s_uni[rr + NMAX];                 // wave-uniform
     COUNT(13, 1)
 #pragma unroll
     for (int dv = 0; dv <= (EXACT ? NMAX : n); dv++) {   // unrolled in the EXACT instance
@@ -293,6 +336,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       if (__ballot(nb != 0) == 0) continue;          // wave-uniform
       COUNT(9, 1)
       const int base = qg * PW + NMAX + lane;
+      if (ul >= 0 && s_uni[qg] == ul) {              // wave-uniform: both rows carry one label, the same — nothing to unite;
+        if (__ballot(!up & (nb != 0)) == 0) continue;   // only pixels that still lack their first up-left edge look for it
+        uint32_t cand2 = __brev(nb) >> (31 - n);
+        if (dv == 0) cand2 &= ~3u;
+        if (dv == 1) cand2 &= ~1u;
+        uint32_t g2 = 0;
+#pragma unroll
+        for (int k = 0; k <= NMAX; k++) g2 |= (fabsf(zp - zt[base - k]) > th) ? 0u : (1u << k);
+        up = up || ((cand2 & g2) != 0);
+        continue;
+      }
       // pass 1, branch-free: labels first, one bit per window position (k = columns to the left)
       int lq[NMAX + 1];
 #pragma unroll
@@ -303,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       // nb holds pixel (lane - n + i) at bit i: reverse it so that bit k = pixel (lane - k)
       uint32_t cand = __brev(nb) >> (31 - n);
       // (0,0) is p itself; (0,-1) inside the wave is the run link of phase A1, (-1,0) the vertical link of phase A2
-      if (dv == 0) cand &= (lane > 0) ? ~3u : ~1u;
+      if (dv == 0) cand &= ~3u;                      // (lane 0: its link to the halo cell left of it was made in phase A1 as well)
       if (dv == 1) cand &= ~1u;
       // Inside a blob that phases A1-A3 already merged, every candidate carries this pixel's label and the pixel has its
       // up-left edge: the depth gate cannot change anything, so its LDS reads and compares are skipped (wave-uniform).
@@ -317,25 +371,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
       for (int k = 0; k <= NMAX; k++) gmask |= (fabsf(zp - zq[k]) > th) ? 0u : (1u << k);   // depthDiff gate (:194); NaN links
       const uint32_t vmask = cand & gmask;
-      // halo cells (the whole row when it lies above the tile, else the columns left of it) are nodes of their own
-      const uint32_t hmask = (qg < NMAX) ? ~0u : ((lane < 31) ? ~((2u << lane) - 1u) : 0u);
-      bool need_any = (vmask & dmask & ~hmask) != 0;
-      const uint32_t hv = vmask & hmask;
-      int hold[NMAX + 1];                            // interior label a halo cell hung under before this pixel hooked it
-#pragma unroll
-      for (int k = 0; k <= NMAX; k++) hold[k] = -1;
-      if (__ballot(hv != 0)) {
-        // hook the halo cell straight under this pixel's label — one LDS atomic instead of a find/unite through the halo
-        // node; if it already hung under another interior label, THAT label's set and this pixel's must meet (pass 2):
-        // the displaced value is the only remaining trace of the older link
-#pragma unroll
-        for (int k = 0; k <= NMAX; k++) {
-          if ((hv >> k) & 1u) {
-            const int old = atomicMin(&Lt[base - k], cur);
-            if (old < kHaloBit && old != cur) { hold[k] = old; need_any = true; }
-          }
-        }
-      }
+      // halo cells are ordinary nodes of the union-find (their ids carry bit 15, so they never become the root of a set that has
+      // a tile pixel); phases A1-A3 have linked them like tile pixels, so they mostly carry this pixel's label already
+      const bool need_any = (vmask & dmask) != 0;
       up = up || (vmask != 0);
       // pass 2, rare after A1-A3: unions, one window position at a time
       if (!MOD_ABLATE(c, 1) && __ballot(need_any)) {
@@ -343,9 +381,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
         for (int k = 0; k <= NMAX; k++) {
           if (k > n || (dv == 0 && k == 0)) continue;
-          const bool ishalo = (hmask >> k) & 1u;
-          const int lab = ishalo ? hold[k] : ld_relaxed(&Lt[base - k]);
-          const bool need = ((vmask >> k) & 1u) && lab >= 0 && lab != cur && lab != last;
+          const int lab = ld_relaxed(&Lt[base - k]);
+          const bool need = ((vmask >> k) & 1u) && lab != cur && lab != last;
           if (__ballot(need)) { COUNT(12, 1) wave_unite_lds(Lt, need, cur, last, lab, lane); }
         }
       }
@@ -400,7 +437,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
         if (gx >= 0 && ((mw >> (gx & 63)) & 1ull)) {
           const int hid = (gr * PW + gc) | kHaloBit;
           const int r = lds_find(Lt, hid);
-          if (r != hid) {                              // linked into a tile component
+          if (!(r & kHaloBit)) {                       // in a component that has a tile pixel (halo cells may also be linked among themselves)
             const int rgr = r / PW, rgc = r - rgr * PW;
             rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
             hg = (y0 - NMAX + gr) * c.W + gx;
