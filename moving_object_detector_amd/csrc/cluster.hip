@@ -438,10 +438,25 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
           const int hid = (gr * PW + gc) | kHaloBit;
           const int r = lds_find(Lt, hid);
           if (!(r & kHaloBit)) {                       // in a component that has a tile pixel (halo cells may also be linked among themselves)
-            const int rgr = r / PW, rgc = r - rgr * PW;
-            rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
-            hg = (y0 - NMAX + gr) * c.W + gx;
-            linked = true;
+            // A halo cell whose left or upper neighbour is a halo cell of the SAME set with a direct edge to it (dynamic, depth gate
+            // passes) leaves the request to that neighbour: the edge between the two is an edge of the image graph that the tile
+            // owning this cell sees itself, so one request per connected group of halo cells (its top-left-most cell) is enough.
+            const float zme = zt[gr * PW + gc];
+            auto covered = [&](int gr2, int gc2) {
+              if (gr2 < NMAX - n || gc2 < NMAX - n) return false;
+              const int gx2 = x0 - NMAX + gc2;
+              const uint64_t mw2 = (gc2 >= NMAX) ? m0[gr2] : mL[gr2];
+              if (gx2 < 0 || !((mw2 >> (gx2 & 63)) & 1ull)) return false;
+              const int cell2 = gr2 * PW + gc2;
+              if (fabsf(zme - zt[cell2]) > th) return false;
+              return lds_find(Lt, cell2 | kHaloBit) == r;
+            };
+            if (!(covered(gr, gc - 1) || covered(gr - 1, gc))) {
+              const int rgr = r / PW, rgc = r - rgr * PW;
+              rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
+              hg = (y0 - NMAX + gr) * c.W + gx;
+              linked = true;
+            }
           }
         }
       }
