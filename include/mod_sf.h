@@ -43,10 +43,12 @@ extern "C" {
 
 typedef struct ModContext ModContext;
 
+#define MOD_MAX_WIDTH 16384   /* the tied-median replay keeps one count per image column of a cluster in LDS */
+
 /* Context creation parameters. */
 typedef struct ModConfig {
   int32_t device;       /* HIP device ordinal */
-  int32_t max_width;    /* largest image width  the scratch is sized for */
+  int32_t max_width;    /* largest image width  the scratch is sized for, <= MOD_MAX_WIDTH */
   int32_t max_height;   /* largest image height the scratch is sized for */
   int32_t max_frames;   /* largest batch (frames per call), <= 65535; max_width * max_height < 2^27 */
   int32_t max_objects;  /* per-frame capacity of the ModObject output; 0 -> max_width*max_height/100 (Clusterer.cfg:8 lower bound).

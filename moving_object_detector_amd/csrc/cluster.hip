@@ -615,8 +615,10 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
     bool keep = (key != kKeyNone) && (size >= c.cluster_size);
     if (keep) {
       const int slot = atomicAdd(&s_n, 1);
-      if (slot < a.max_objects) { T[slot].comp = r; T[slot].size = size; T[slot].offset = key; }
-      else { a.counters[f * 8 + 3] = 2; keep = false; }   // more clusters than max_objects: the excess is dropped (flagged)
+      // capacity: mod_set_params admits a cluster_size only if max_width * max_height / cluster_size clusters fit max_objects,
+      // so this cannot overflow (asserted in the checked build, code 15)
+      if (MOD_CHECK(a, slot < a.max_objects, 15) && slot < a.max_objects) { T[slot].comp = r; T[slot].size = size; T[slot].offset = key; }
+      else keep = false;
     }
     if (!keep) rkey[r] = -1;
   }
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
 // not after it, so ranks from two prefix counts give every swap at once — and the finished (<= 16 element) range gets the
 // stable insertion sort.  Rare path: one workgroup per flagged cluster, nothing to do for the others.
 // Scratch (all dead by now): keys -> parent plane, pixels -> rsize plane, swap lists -> the member arrays.
-constexpr int kTieThreads = 1024, kTieCols = 2048, kTieLds = 8192;
+constexpr int kTieThreads = 1024, kTieCols = 16384, kTieLds = 8192;   // kTieCols: 2 * kTieLds counts, one per column at the least
 
 struct TieShared {           // control block of one workgroup of k_median_ties
   int cntA[kTieThreads / 64], cntB[kTieThreads / 64];
@@ -1284,7 +1286,7 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
       TSTAMP(22)
     } else {
     // Fallback for bounding boxes with more than kTieLds cells: scan the box in the image.
-    if (ncols > kTieCols) continue;                  // wider than the column table: keep the canonical pick (stays flagged)
+    if (ncols > kTieCols) { (void)MOD_CHECK(a, false, 14); continue; }   // cannot happen: mod_create rejects images wider than MOD_MAX_WIDTH = kTieCols
     // ---- members in column-major order: count, prefix, fill.  The bounding box is cut into (64-column chunk, row segment)
     // work items so that all 16 waves are busy; a wave reads 4 rows of its chunk at a time (coalesced, 4-16 reads in flight).
     // Counts live in the LDS arrays of the later LDS phase: cc[segment][column] ----
@@ -1312,21 +1314,22 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     __syncthreads();
     TSTAMP(21)
     if (MOD_ABLATE(c, 1 << 21)) continue;
-    // exclusive prefix in column-major order: columns left to right, inside a column the segments top to bottom
+    // exclusive prefix in column-major order: columns left to right, inside a column the segments top to bottom.
+    // Thread t owns the cpt consecutive columns t * cpt ... (cpt = 2 up to 2048 columns, at most kTieCols / kTieThreads = 16)
     {
-      int tot0 = 0, tot1 = 0;                                        // thread t owns columns 2t and 2t+1
-      const int c0 = 2 * tid, c1 = 2 * tid + 1;
-      for (int sg = 0; sg < nseg; sg++) { if (c0 < ncp) tot0 += CC(sg, c0); if (c1 < ncp) tot1 += CC(sg, c1); }
-      int incl = tot0 + tot1;
+      const int cpt = max(2, (ncp + kTieThreads - 1) / kTieThreads), cbeg = tid * cpt;
+      int tot = 0;
+      for (int u = 0; u < cpt; u++) { const int cx = cbeg + u; if (cx < ncp) for (int sg = 0; sg < nseg; sg++) tot += CC(sg, cx); }
+      int incl = tot;
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
       if (lane == 63) sh.cntA[wv] = incl;
       __syncthreads();
       if (tid == 0) { int run = 0; for (int t = 0; t < kTieThreads / 64; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; } }
       __syncthreads();
-      int start0 = sh.cntA[wv] + incl - tot0 - tot1, start1 = start0 + tot0;
-      for (int sg = 0; sg < nseg; sg++) {
-        if (c0 < ncp) { const int t = CC(sg, c0); CC(sg, c0) = start0; start0 += t; }
-        if (c1 < ncp) { const int t = CC(sg, c1); CC(sg, c1) = start1; start1 += t; }
+      int start = sh.cntA[wv] + incl - tot;
+      for (int u = 0; u < cpt; u++) {
+        const int cx = cbeg + u;
+        if (cx < ncp) for (int sg = 0; sg < nseg; sg++) { const int t = CC(sg, cx); CC(sg, cx) = start; start += t; }
       }
     }
     __syncthreads();

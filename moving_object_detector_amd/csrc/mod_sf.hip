@@ -311,7 +311,7 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   if (cfg->max_width < 1 || cfg->max_height < 1 || cfg->max_frames < 1) return MOD_ERR_INVALID_ARGUMENT;
   // launch geometry and index widths: frames ride in grid.y / grid.z (<= 65535), the scene-flow kernel addresses a frame's
   // planes with 32-bit byte offsets (32 B/px for the AoS cloud), cluster work items are frame * max_objects + cluster in 32 bits
-  if (cfg->max_frames > 65535) return MOD_ERR_INVALID_ARGUMENT;
+  if (cfg->max_frames > 65535 || cfg->max_width > MOD_MAX_WIDTH) return MOD_ERR_INVALID_ARGUMENT;
   if ((uint64_t)cfg->max_width * (uint64_t)cfg->max_height >= (1ull << 27)) return MOD_ERR_INVALID_ARGUMENT;
   if (cfg->max_objects > 0 && (uint64_t)cfg->max_objects * (uint64_t)cfg->max_frames >= (1ull << 31)) return MOD_ERR_INVALID_ARGUMENT;
   int ndev = 0;

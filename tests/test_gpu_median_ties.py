@@ -46,3 +46,21 @@ def test_tied_median_matches_std_sort(oracle, case):
     assert K == rK and np.array_equal(lab, rl)
     assert any(o["ambiguous"] for o in ro), "the case is meant to produce ties between different vectors"
     compare_objects(objs, ro, strict_velocity=True)
+
+
+@pytest.mark.parametrize("W,H", [(8256, 8), (2304, 260)])
+def test_tied_median_of_a_very_wide_cluster(oracle, W, H):
+    """A flagged cluster whose bounding box has more than 8192 (column x 64-row) cells takes k_median_ties' image-scan layout; its
+    column table covers up to MOD_MAX_WIDTH = 16384 columns (round 1 gave up beyond 2048 and kept the canonical pick)."""
+    from moving_object_detector_amd import synth
+    from test_gpu_cluster_stress import _cluster_gpu
+    rng = np.random.default_rng(W)
+    dyn = rng.random((H, W)) < 0.97
+    dyn[:, :3] = False
+    prm = synth.Params(cluster_size=1000, neighbor_distance=4)
+    planes = _tie_cloud(W, H, rng, dyn, 2)
+    lab, objs, K = _cluster_gpu(planes, prm, W, H)
+    rl, ro, rK = oracle.cluster(planes, prm, "tidy", max_objects=W * H)
+    assert K == rK == 1 and np.array_equal(lab, rl)
+    assert ro[0]["ambiguous"] and ro[0]["n_points"] > 8192
+    compare_objects(objs, ro, strict_velocity=True)
