@@ -239,8 +239,10 @@ def main():
         dom_bytes = F * N * (B_SCENE_FLOW if dom == capi.MOD_STAGE_SCENE_FLOW else B_CLUSTER)
         ach = dom_bytes / (ms[dom] * 1e-3) / 1e9
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")              # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        if os.path.exists(tpath):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tpath = tfiles[-1] if tfiles else None                                          # the latest round's
+        if tpath:
             tj = json.load(open(tpath))
             if tj.get("frames_per_launch") == F and tj.get("width") == W and tj.get("height") == H:
                 traffic = tj["kernels"].get(capi.STAGE_NAMES[dom].split("+")[0], {}).get("hbm_bytes_per_launch")
@@ -251,7 +253,8 @@ def main():
             "frames_per_launch": F, "avg_launch_ms": ms[dom],
             "measured_in": "timed region" if dom == capi.MOD_STAGE_SCENE_FLOW else "breakdown pass (all stage timers on)",
             "scene_flow_ms_in_breakdown_pass": breakdown_sf_ms, "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
-            "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 + WRITE_SIZE, same command)" if traffic else None,
+            "traffic_source": (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 + WRITE_SIZE, same command)"
+                               if traffic else None),
             "kernels_ms_per_launch": kernels,
             "groups": {
                 "scene_flow": {"ms_per_launch": sf_ms, "GBps": sf_gbs, "frac": sf_gbs / HBM_PEAK_GBS, "bytes_per_px": B_SCENE_FLOW},
