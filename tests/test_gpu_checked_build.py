@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 
 def test_no_index_violation_on_the_critical_shapes():
     lib = os.path.join(ROOT, "moving_object_detector_amd", "libmod_sf_checked.so")
-    assert os.path.exists(lib), "build it with __graft_entry__.build() or `make -C moving_object_detector_amd/csrc checked`"
+    if not os.path.exists(lib):                                # normally built by __graft_entry__.build(); hipcc is on the GPU box too
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "moving_object_detector_amd", "csrc"), "checked"], stdout=subprocess.DEVNULL)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checked_worker.py")], env=dict(os.environ, MOD_SF_LIB=lib),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

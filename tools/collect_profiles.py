@@ -31,6 +31,25 @@ for k, d in per.items():
     traffic["kernels"][name] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
                                 "raw_FETCH_SIZE": d.get("FETCH_SIZE"), "raw_WRITE_SIZE": d.get("WRITE_SIZE")}
 json.dump(traffic, open(f"profiles/{tag.split('_')[0]}_traffic.json", "w"), indent=1)
+# extra bench lines + SQ counters (64-frame dispatches) of the two main kernels
+extra = {}
+for name in ("pairs", "64", "kitti"):
+    try:
+        j = json.loads(open(f"{src}/bench_{name}.json").read().strip().splitlines()[-1])
+        extra[name] = {"value": j["value"], "ms_per_step": j["ms_per_step"], "frames_per_step": j["config"]["frames_per_step_per_gpu"],
+                       "scene_flow_frac": j["roofline"]["groups"]["scene_flow"]["frac"], "kernels_ms_per_launch": j["roofline"]["kernels_ms_per_launch"]}
+    except Exception as e:
+        extra[name] = {"error": str(e)}
+sq = collections.defaultdict(dict)
+for d in sorted(glob.glob(f"{src}/pmc_sq*")):
+    if not os.path.isdir(d): continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for fcsv in glob.glob(f"{d}/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(fcsv)):
+            m = re.search(r"(k_scene_flow\w*|k_ccl_tile|k_final|k_median\b|k_ccl_link)", r["Kernel_Name"])
+            if m: agg[(m.group(1), r["Counter_Name"])][0] += 1; agg[(m.group(1), r["Counter_Name"])][1] += float(r["Counter_Value"])
+    for (k, cn), (n, v) in agg.items(): sq[k][cn] = v / n
+json.dump({"other_bench_lines": extra, "sq_counters_per_64_frame_dispatch": sq}, open(f"profiles/{tag}_extra.json", "w"), indent=1)
 print("value", bench["value"], "pairs/s;", bench["roofline"]["kernel"], "frac", round(bench["roofline"]["frac"], 3))
 for r in rows:
     if float(r["Percentage"]) > 0.3: print("%-62s calls %4s avg_us %9.2f %6s%%" % (r["Name"][:62], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
