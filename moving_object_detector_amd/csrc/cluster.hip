@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __shared__ uint64_t m0[PH], mL[PH];
   __shared__ int s_uni[PH];                         // the one label every dynamic cell of the grid row carries after phase A3, or -1
   constexpr int kSlots = 32;
-  __shared__ int s_any, s_nreq, s_nslots;
+  __shared__ int s_nreq, s_nslots;
   __shared__ RootRec srec[kSlots];
   __shared__ int sroot[kSlots];
   // threadIdx.y is the wave index: the same in all 64 lanes, but it arrives in a vector register — as a scalar, every row
@@ -158,25 +158,34 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   const int MW = c.mask_words, n = EXACT ? NMAX : c.n;
   const size_t N = (size_t)c.W * c.H;
   const size_t fN = (size_t)f * N;
-  if (tid == 0) { s_any = 0; s_nreq = 0; s_nslots = 0; }
-  __syncthreads();
+  // The tile's header says whether it holds a dynamic pixel at all (written with the mask words: by the scene-flow kernel's
+  // epilogue, or by k_tile_flags).  Three quarters of the tiles of a street scene do not: they cost one scalar load.
+  int *hdr = a.tilehdr + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * 2;
+  if (__builtin_amdgcn_readfirstlane(hdr[0]) == 0) return;
+  if (tid == 0) { s_nreq = 0; s_nslots = 0; }
+  // ---- all HBM reads of the kernel, in ONE round trip: the mask words of the PH grid rows and the depth rows (unconditional,
+  // clamped addresses; values of non-dynamic pixels are discarded: predicated loads would compile to one exec-masked branch +
+  // wait each) ----
   if (tid < PH) {
     const int gy = y0 - NMAX + tid;
     const bool inrow = gy >= 0 && gy < c.H && tid >= NMAX - n;
     const uint64_t *mr = a.mask + ((size_t)f * c.H + (inrow ? gy : 0)) * MW;
-    const uint64_t v0 = inrow ? mr[wi] : 0ull;
-    m0[tid] = v0;
+    m0[tid] = inrow ? mr[wi] : 0ull;
     mL[tid] = (inrow && wi > 0) ? mr[wi - 1] : 0ull;
-    if (tid >= NMAX && v0) s_any = 1;
+  }
+  constexpr int AROWS = (PH + NW - 1) / NW;
+  float zl[AROWS], zh[AROWS];
+  const int xc = min(x0 + lane, c.W - 1), xhc = max(x0 - 1 - lane, 0);
+#pragma unroll
+  for (int i = 0; i < AROWS; i++) {
+    const int gy = min(max(y0 - NMAX + w + NW * i, 0), c.H - 1);
+    const size_t rowp = fN + (size_t)gy * c.W;
+    zl[i] = a.z[rowp + xc];
+    zh[i] = a.z[rowp + xhc];                          // left halo: column x0 - 1 - lane (lanes < n)
   }
   __syncthreads();
   // rows are dealt to the waves round-robin (wave w owns rows w, w + 4, ...): a blob's rows are contiguous, so contiguous
   // row blocks would leave most of a tile's work to one wave while the others wait at the barriers
-  int *hdr = a.tilehdr + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * 2;
-  if (!s_any) {                                     // nothing dynamic inside the tile
-    if (tid == 0) { hdr[0] = 0; hdr[1] = 0; }
-    return;
-  }
   const float th = c.depth_th;
 #ifdef MOD_PHASE_COUNTERS   // diagnostic build only (make PHASE_COUNTERS=1): per-phase cycle sums in ClArgs.dbg
   const bool prof = c.debug & 128;
@@ -191,18 +200,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #define COUNT(i, v)
 #endif
   // ---- phase A: masked depth + identity parents; grid row gr = image row y0 - NMAX + gr, 4 rows per step -----------
-  // All HBM reads of the kernel are issued here, unconditionally (clamped addresses, values of non-dynamic pixels are
-  // discarded): predicated loads would compile to one exec-masked branch + wait each, i.e. one round trip per row.
-  constexpr int AROWS = (PH + NW - 1) / NW;
-  float zl[AROWS], zh[AROWS];
-  const int xc = min(x0 + lane, c.W - 1), xhc = max(x0 - 1 - lane, 0);
-#pragma unroll
-  for (int i = 0; i < AROWS; i++) {
-    const int gy = min(max(y0 - NMAX + w + NW * i, 0), c.H - 1);
-    const size_t rowp = fN + (size_t)gy * c.W;
-    zl[i] = a.z[rowp + xc];
-    zh[i] = a.z[rowp + xhc];                          // left halo: column x0 - 1 - lane (lanes < n)
-  }
 #pragma unroll
   for (int i = 0; i < AROWS; i++) {
     const int gr = w + NW * i;
@@ -516,7 +513,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   STAMP(8)
 #undef STAMP
 #undef COUNT
-  if (tid == 0) { hdr[0] = 1; hdr[1] = s_nreq; }   // s_nreq is final: the barrier after the request loop has passed
+  if (tid == 0) hdr[1] = s_nreq;                   // s_nreq is final: the barrier after the request loop has passed (hdr[0] is 1 already)
+}
+
+// Tile headers from a mask plane that did not come out of the fused scene-flow kernel (mod_cluster_dev): {1, 0} for tiles with a
+// dynamic pixel, {0, 0} for the others.  One thread per tile.
+template <int TH>
+__global__ __launch_bounds__(256) void k_tile_flags(DevCam c, ClArgs a, int tiles_x, int tiles_per_frame, int total) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int f = t / tiles_per_frame, tt = t - f * tiles_per_frame, ty = tt / tiles_x, wi = tt - ty * tiles_x;
+  const uint64_t *m = a.mask + ((size_t)f * c.H + (size_t)ty * TH) * c.mask_words + wi;
+  const int rows = min(TH, c.H - ty * TH);
+  uint64_t any = 0;
+#pragma unroll 4
+  for (int r = 0; r < rows; r++) any |= m[(size_t)r * c.mask_words];
+  a.tilehdr[(size_t)t * 2] = any != 0 ? 1 : 0;
+  a.tilehdr[(size_t)t * 2 + 1] = 0;
 }
 
 // Cross-tile links.  One workgroup per kLinkTiles consecutive tiles (most tiles have no dynamic pixel and no request: a
@@ -1426,6 +1439,11 @@ void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
   else if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, false>), tgrid, block, 0, s, c, a);
   else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves, false>), tgrid, block, 0, s, c, a);
   else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16, kTileWaves, false>), tgrid, block, 0, s, c, a);
+}
+void launch_tile_flags(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
+  const dim3 g = tile_grid(c, frames);
+  const int tiles = (int)(g.x * g.y), total = tiles * frames;
+  hipLaunchKernelGGL(k_tile_flags<kTileH>, dim3((total + 255) / 256), dim3(256), 0, s, c, a, (int)g.x, tiles, total);
 }
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 g = tile_grid(c, frames);

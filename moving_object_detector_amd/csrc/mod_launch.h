@@ -10,6 +10,8 @@ struct SfArgs {
   float *depth;                       // [F][H][W] or null
   float *sflow;                       // [F][H][W][2] or null
   const FrameConst *fc;               // [F] device
+  int32_t *tilehdr;                   // [F][tiles][2] or null: header word 0 of every cluster tile with a dynamic pixel is set to 1
+  int32_t tile_rows, tiles_x, tiles_per_frame;   // (zeroed by the caller beforehand); tile = 64 x tile_rows pixels
 };
 
 // Scratch the clustering kernels work in; all device pointers, sized by the context.
@@ -35,7 +37,7 @@ struct ClArgs {
   int32_t *n_clusters;        // [F] or null
   int32_t max_objects;
   uint2 *requests;            // [F][tiles][req_cap] cross-tile link requests (halo pixel, tile root)
-  int32_t *tilehdr;           // [F][tiles][2]: active flag, number of requests
+  int32_t *tilehdr;           // [F][tiles][2]: the tile has a dynamic pixel (set together with the mask words), number of requests
   int32_t req_cap;
   unsigned long long *dbg;    // [32] cycle counters, only touched when DevCam.debug & 128
 };
@@ -50,6 +52,7 @@ void launch_unpack(size_t n, const void *aos, float *x, float *y, float *z, floa
 
 // clustering kernels, one launcher per timed stage (include/mod_sf.h MOD_STAGE_*)
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+void launch_tile_flags(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);   // tile headers from a mask plane
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);

@@ -248,7 +248,7 @@ int check_batch(ModContext *c, const ModFrameBatch *in) {
   return MOD_OK;
 }
 
-int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask) {
+int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask, bool tile_flags) {
   if (!out || !out->x || !out->y || !out->z || !out->vx || !out->vy || !out->vz)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "scene-flow output planes x,y,z,vx,vy,vz are required");
   int rc = upload_frame_consts(c, in);
@@ -258,6 +258,12 @@ int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPla
   a.x = out->x; a.y = out->y; a.z = out->z; a.vx = out->vx; a.vy = out->vy; a.vz = out->vz;
   a.mask = mask; a.aos = (float4 *)out->cloud_aos; a.depth = out->depth; a.sflow = out->static_flow;
   a.fc = c->b.fc;
+  a.tilehdr = nullptr; a.tile_rows = ccl_tile_rows(); a.tiles_x = c->dc.mask_words;
+  a.tiles_per_frame = c->dc.mask_words * ((c->dc.H + ccl_tile_rows() - 1) / ccl_tile_rows());
+  if (tile_flags && mask) {      // the clustering follows: the kernel's epilogue also marks the cluster tiles that hold a dynamic pixel
+    a.tilehdr = c->b.tilehdr;
+    HIP_TRY(c, hipMemsetAsync(c->b.tilehdr, 0, sizeof(int32_t) * 2 * (size_t)a.tiles_per_frame * in->frames, c->stream));
+  }
   {
     StageTimer t(c, MOD_STAGE_SCENE_FLOW);
     launch_scene_flow(c->dc, a, in->frames, c->stream);
@@ -266,7 +272,7 @@ int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPla
   return MOD_OK;
 }
 
-int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready,
+int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready, bool flags_ready,
                 const ModClusterOut *out) {
   if (!pl || !pl->x || !pl->y || !pl->z || !pl->vx || !pl->vy || !pl->vz)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster input planes x,y,z,vx,vy,vz are required");
@@ -283,6 +289,7 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   {
     StageTimer t(c, MOD_STAGE_CCL_TILE);
     if (!mask_ready) launch_dynamic_mask(c->dc, frames, pl->vx, pl->vy, pl->vz, (uint64_t *)mask, c->stream);
+    if (!flags_ready) launch_tile_flags(c->dc, a, frames, c->stream);
     HIP_TRY(c, hipMemsetAsync(c->b.counters, 0, sizeof(int32_t) * 8 * frames, c->stream));
     launch_ccl_tile(c->dc, a, frames, c->stream);
   }
@@ -467,7 +474,7 @@ static int depth_on_skip(ModContext *c, int skip, const ModFrameBatch *in, const
 int mod_scene_flow_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out) {
   int rc = check_batch(c, in);
   if (rc) return depth_on_skip(c, rc, in, out);
-  return run_scene_flow(c, in, out, out ? out->dynamic_mask : nullptr);
+  return run_scene_flow(c, in, out, out ? out->dynamic_mask : nullptr, false);
 }
 
 int mod_depth_image_dev(ModContext *c, int32_t frames, const float *disparity_now, float *depth) {
@@ -493,16 +500,16 @@ int mod_cluster_dev(ModContext *c, int32_t frames, const ModSceneFlowPlanes *pl,
   int rc = check_ready(c, frames);
   if (rc) return rc;
   const bool have = pl && pl->dynamic_mask;
-  return run_cluster(c, frames, pl, have ? pl->dynamic_mask : c->b.mask, have, out);
+  return run_cluster(c, frames, pl, have ? pl->dynamic_mask : c->b.mask, have, false, out);
 }
 
 int mod_process_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *pl, const ModClusterOut *out) {
   int rc = check_batch(c, in);
   if (rc) return depth_on_skip(c, rc, in, pl);
   uint64_t *mask = (pl && pl->dynamic_mask) ? pl->dynamic_mask : c->b.mask;
-  rc = run_scene_flow(c, in, pl, mask);
+  rc = run_scene_flow(c, in, pl, mask, true);
   if (rc) return rc;
-  return run_cluster(c, in->frames, pl, mask, true, out);
+  return run_cluster(c, in->frames, pl, mask, true, true, out);
 }
 
 int mod_pack_cloud_dev(ModContext *c, int32_t frames, const ModSceneFlowPlanes *pl, void *aos) {

@@ -277,8 +277,10 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   if (a.mask) {   // wave-uniform branch; all 64 lanes take part in the shuffles
     const uint64_t w = nibbles_to_word(nib, lane);
     const int word = (bx * 64 + lane) / 16;                  // (x0 / 64)
-    if ((lane & 15) == 0 && y < c.H && word < c.mask_words)
+    if ((lane & 15) == 0 && y < c.H && word < c.mask_words) {
       a.mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
+      if (a.tilehdr && w) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + word) * 2] = 1;   // benign race: every writer stores 1
+    }
   }
 }
 
@@ -339,8 +341,11 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
     v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
     const uint32_t hi = __shfl_down(v, 16);
     const int word = blockIdx.x * 2 + (lane >> 5);
-    if ((lane & 31) == 0 && y < c.H && word < c.mask_words)
-      a.mask[((size_t)f * c.H + y) * c.mask_words + word] = (uint64_t)v | ((uint64_t)hi << 32);
+    if ((lane & 31) == 0 && y < c.H && word < c.mask_words) {
+      const uint64_t wd = (uint64_t)v | ((uint64_t)hi << 32);
+      a.mask[((size_t)f * c.H + y) * c.mask_words + word] = wd;
+      if (a.tilehdr && wd) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + word) * 2] = 1;
+    }
   }
 }
 
@@ -366,7 +371,10 @@ __global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) {
   }
   if (a.mask) {
     const uint64_t w = __ballot(dyn);
-    if (lane == 0 && y < c.H && blockIdx.x < (unsigned)c.mask_words) a.mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x] = w;
+    if (lane == 0 && y < c.H && blockIdx.x < (unsigned)c.mask_words) {
+      a.mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x] = w;
+      if (a.tilehdr && w) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + blockIdx.x) * 2] = 1;
+    }
   }
 }
 
