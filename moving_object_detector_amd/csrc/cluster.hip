@@ -318,12 +318,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     int cur = dyn ? ld_relaxed(&Lt[me]) : -1, last = -1;
     bool up = upr[j];
     const int ul = s_uni[rr + NMAX];                 // wave-uniform
+    bool rowup = __ballot(dyn & !up) == 0;           // every dynamic pixel of the row has an up-left edge (wave-uniform)
     COUNT(13, 1)
 #pragma unroll
     for (int dv = 0; dv <= (EXACT ? NMAX : n); dv++) {   // unrolled in the EXACT instance
       const int qg = rr + NMAX - dv;                 // grid row of the window row
       const uint64_t q0 = m0[qg], qL = mL[qg];
       if ((q0 | qL) == 0) continue;                  // wave-uniform
+      // both rows carry one label, the same (phase A3's summaries): nothing to unite; when every pixel of the row has its
+      // up-left edge already, the window row is of no interest at all (wave-uniform, scalar)
+      const bool same = ul >= 0 && s_uni[qg] == ul;
+      if (same && rowup) continue;
       // bit i of nb = pixel (lane - n + i) of the window row is dynamic  (i = n - k)
       uint32_t nb;
       if (lane >= n) nb = (uint32_t)(q0 >> (lane - n));
@@ -333,8 +338,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       if (__ballot(nb != 0) == 0) continue;          // wave-uniform
       COUNT(9, 1)
       const int base = qg * PW + NMAX + lane;
-      if (ul >= 0 && s_uni[qg] == ul) {              // wave-uniform: both rows carry one label, the same — nothing to unite;
-        if (__ballot(!up & (nb != 0)) == 0) continue;   // only pixels that still lack their first up-left edge look for it
+      if (same) {                                    // only pixels that still lack their first up-left edge look for it
+        if (__ballot(!up & (nb != 0)) == 0) continue;
         uint32_t cand2 = __brev(nb) >> (31 - n);
         if (dv == 0) cand2 &= ~3u;
         if (dv == 1) cand2 &= ~1u;
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #pragma unroll
         for (int k = 0; k <= NMAX; k++) g2 |= (fabsf(zp - zt[base - k]) > th) ? 0u : (1u << k);
         up = up || ((cand2 & g2) != 0);
+        rowup = __ballot(dyn & !up) == 0;
         continue;
       }
       // pass 1, branch-free: labels first, one bit per window position (k = columns to the left)
@@ -416,42 +422,54 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
   STAMP(5)
   // halo pixels that ended up in a tile component belong to other tiles, whose roots are not known yet: leave one link
-  // request (halo pixel, tile root) each for k_ccl_link
+  // request (halo pixel, tile root) per connected group of them for k_ccl_link.  First every halo cell is flattened to its root
+  // (no union runs any more), so that the neighbour tests below are plain LDS reads.
   {
     const int topcells = n * (64 + n);               // n rows x (n + 64) columns above the tile
     const int total = topcells + TH * n;             // + TH rows x n columns left of it
+    auto cell_of = [&](int i, int &gr, int &gc) {
+      if (i < topcells) { gr = NMAX - n + i / (64 + n); gc = NMAX - n + i % (64 + n); }
+      else { const int t = i - topcells; gr = NMAX + t / n; gc = NMAX - n + t % n; }
+    };
+    auto halo_dyn = [&](int gr, int gc) {
+      const int gx = x0 - NMAX + gc;
+      const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
+      return gx >= 0 && ((mw >> (gx & 63)) & 1ull);
+    };
+    const bool any_halo = !MOD_ABLATE(c, 1024);
+    for (int i0 = 0; i0 < total && any_halo; i0 += NW * 64) {
+      const int i = i0 + tid;
+      if (i < total) {
+        int gr, gc;
+        cell_of(i, gr, gc);
+        if (halo_dyn(gr, gc)) { const int cell = gr * PW + gc; Lt[cell] = lds_find(Lt, cell | kHaloBit); }
+      }
+    }
+    lds_barrier();
     uint2 *req = a.requests + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * a.req_cap;
-    for (int i0 = 0; i0 < total && !MOD_ABLATE(c, 1024); i0 += NW * 64) {
+    for (int i0 = 0; i0 < total && any_halo; i0 += NW * 64) {
       const int i = i0 + tid;
       bool linked = false;
       int hg = 0, rg = 0;
       if (i < total) {
         int gr, gc;
-        if (i < topcells) { gr = NMAX - n + i / (64 + n); gc = NMAX - n + i % (64 + n); }
-        else { const int t = i - topcells; gr = NMAX + t / n; gc = NMAX - n + t % n; }
-        const int gx = x0 - NMAX + gc;
-        const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
-        if (gx >= 0 && ((mw >> (gx & 63)) & 1ull)) {
-          const int hid = (gr * PW + gc) | kHaloBit;
-          const int r = lds_find(Lt, hid);
+        cell_of(i, gr, gc);
+        if (halo_dyn(gr, gc)) {
+          const int r = Lt[gr * PW + gc];
           if (!(r & kHaloBit)) {                       // in a component that has a tile pixel (halo cells may also be linked among themselves)
             // A halo cell whose left or upper neighbour is a halo cell of the SAME set with a direct edge to it (dynamic, depth gate
             // passes) leaves the request to that neighbour: the edge between the two is an edge of the image graph that the tile
             // owning this cell sees itself, so one request per connected group of halo cells (its top-left-most cell) is enough.
             const float zme = zt[gr * PW + gc];
             auto covered = [&](int gr2, int gc2) {
-              if (gr2 < NMAX - n || gc2 < NMAX - n) return false;
-              const int gx2 = x0 - NMAX + gc2;
-              const uint64_t mw2 = (gc2 >= NMAX) ? m0[gr2] : mL[gr2];
-              if (gx2 < 0 || !((mw2 >> (gx2 & 63)) & 1ull)) return false;
+              if (gr2 < NMAX - n || gc2 < NMAX - n || !halo_dyn(gr2, gc2)) return false;
               const int cell2 = gr2 * PW + gc2;
-              if (fabsf(zme - zt[cell2]) > th) return false;
-              return lds_find(Lt, cell2 | kHaloBit) == r;
+              return !(fabsf(zme - zt[cell2]) > th) && Lt[cell2] == r;
             };
             if (!(covered(gr, gc - 1) || covered(gr - 1, gc))) {
               const int rgr = r / PW, rgc = r - rgr * PW;
               rg = (y0 + rgr - NMAX) * c.W + x0 + rgc - NMAX;
-              hg = (y0 - NMAX + gr) * c.W + gx;
+              hg = (y0 - NMAX + gr) * c.W + x0 - NMAX + gc;
               linked = true;
             }
           }
