@@ -695,7 +695,11 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
 // plane is written here, 4 B/px).  A pixel's parent entry names its tile root, so the few tile roots resolve their final
 // root's new label once (into LDS) and every pixel just looks it up; members of surviving clusters are counted per tile
 // root in LDS, one cursor atomic per (tile root) reserves their slots, then (||v|| bits, pixel) records are appended.
-template <int TH, int NW>
+// XY_FROM_Z: the planes come from the fused scene-flow kernel of the same call (mod_process_dev), where every valid pixel has
+// x = F32(ray_x(column) * (double)z), y = F32(ray_y(row) * (double)z) (sceneflow.hip sf_stage1, getPoint3D): the members' x, y are
+// then recomputed from z and the ray tables — the same two operations, the same bits — instead of being read back (8 B/px of the
+// active tiles less for this HBM-bound kernel).  Caller-supplied clouds (mod_cluster_dev) are read as they are.
+template <int TH, int NW, bool XY_FROM_Z>
 __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   constexpr int RPW = TH / NW;
   __shared__ int nlmap[TH * 64];                     // per tile-root cell: new label of its component (or -1)
@@ -780,7 +784,17 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
     for (int j = 0; j < RPW; j++) {
       const size_t gp = fN + (size_t)min(y0 + r0 + j, c.H - 1) * c.W + xc;
       vx[j] = a.vx[gp]; vy[j] = a.vy[gp]; vz[j] = a.vz[gp];
-      px[j] = a.x[gp]; py[j] = a.y[gp]; pz[j] = a.z[gp];
+      pz[j] = a.z[gp];
+      if (!XY_FROM_Z) { px[j] = a.x[gp]; py[j] = a.y[gp]; }
+    }
+    if (XY_FROM_Z) {
+      const double rx = c.rayx[xc];
+#pragma unroll
+      for (int j = 0; j < RPW; j++) {
+        const double zd = (double)pz[j];
+        px[j] = (float)(rx * zd);
+        py[j] = (float)(c.rayy[min(y0 + r0 + j, c.H - 1)] * zd);
+      }
     }
   }
   lds_barrier();
@@ -1479,7 +1493,8 @@ void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) 
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
 }
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  hipLaunchKernelGGL((k_final<kTileH, kTileWaves>), tile_grid(c, frames), dim3(64, kTileWaves, 1), 0, s, c, a);
+  if (a.xy_from_z) hipLaunchKernelGGL((k_final<kTileH, kTileWaves, true>), tile_grid(c, frames), dim3(64, kTileWaves, 1), 0, s, c, a);
+  else hipLaunchKernelGGL((k_final<kTileH, kTileWaves, false>), tile_grid(c, frames), dim3(64, kTileWaves, 1), 0, s, c, a);
 }
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // one 1024-thread workgroup fills a CU and costs ~80 ns of wave dispatch whether it finds work or not: launch at most one

@@ -36,6 +36,7 @@ struct ClArgs {
   int32_t *n_objects;         // [F]
   int32_t *n_clusters;        // [F] or null
   int32_t max_objects;
+  int32_t xy_from_z;          // the planes are the fused scene-flow kernel's of this call: x, y of a valid pixel are functions of z
   uint2 *requests;            // [F][tiles][req_cap] cross-tile link requests (halo pixel, tile root)
   int32_t *tilehdr;           // [F][tiles][2]: the tile has a dynamic pixel (set together with the mask words), number of requests
   int32_t req_cap;

@@ -285,6 +285,7 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.cursors = c->b.cursors; a.worklist = c->b.worklist; a.tielist = c->b.worklist + (size_t)c->cfg.max_frames * c->max_objects;
   a.objects = out->objects; a.n_objects = out->n_objects;
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
+  a.xy_from_z = flags_ready ? 1 : 0;                  // only mod_process_dev's fused path hands over its own scene-flow planes
   a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
   {
     StageTimer t(c, MOD_STAGE_CCL_TILE);
