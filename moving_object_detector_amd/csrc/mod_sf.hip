@@ -44,8 +44,8 @@ struct Buffers {
   // on-GPU disparity (allocated on first use)
   uint32_t *sgm_census = nullptr;
   uint8_t *sgm_maps = nullptr;
-  uint16_t *sgm_S = nullptr;
-  int sgm_D = 0;
+  uint8_t *sgm_S = nullptr;                 // [paths][group][H][W][D] path cost volumes
+  int sgm_D = 0, sgm_G = 0;                 // disparities / frames per group the scratch is sized for
 };
 
 }  // namespace
@@ -563,19 +563,28 @@ int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left,
   return MOD_OK;
 }
 
-// scratch of the complete estimator, for ONE frame (frames of a batch are processed one after the other on the stream):
-// two census planes, the summed cost volume (uint16), four disparity maps
-static int ensure_sgm_scratch(ModContext *c, int D) {
+// scratch of the complete estimator for a GROUP of frames (one wave walks a path line, so a single frame cannot fill the GPU; the
+// frames of a group run side by side): per frame two census planes, one uint8 cost volume PER PATH (written once, never read
+// back by the path kernels: a running sum would put its load latency into every step of a path), four disparity maps
+constexpr int kSgmGroup = 8, kSgmPaths = 8;
+constexpr size_t kSgmVolumeBudget = (size_t)24 << 30;    // bytes of cost volumes a context may hold
+
+static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
   Buffers &b = c->b;
   const size_t N = c->maxN;
-  if (b.sgm_S && b.sgm_D >= D) return MOD_OK;
+  int g = std::min(frames, kSgmGroup);
+  while (g > 1 && (size_t)g * N * D * kSgmPaths > kSgmVolumeBudget) g--;
+  *group = g;
+  if (b.sgm_S && b.sgm_D >= D && b.sgm_G >= g) return MOD_OK;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (b.sgm_S) { HIP_TRY(c, hipFree(b.sgm_S)); b.sgm_S = nullptr; }
-  b.sgm_D = 0;
-  HIP_TRY(c, dalloc(&b.sgm_census, 2 * N));
-  HIP_TRY(c, dalloc(&b.sgm_maps, 4 * N));
-  HIP_TRY(c, dalloc(&b.sgm_S, N * (size_t)D));
-  b.sgm_D = D;
+  void *old[] = {b.sgm_S, b.sgm_census, b.sgm_maps};
+  for (void *q : old) if (q) HIP_TRY(c, hipFree(q));
+  b.sgm_S = nullptr; b.sgm_census = nullptr; b.sgm_maps = nullptr; b.sgm_D = 0; b.sgm_G = 0;
+  const int D2 = std::max(D, b.sgm_D), g2 = std::max(g, b.sgm_G);
+  HIP_TRY(c, dalloc(&b.sgm_census, 2 * N * g2));
+  HIP_TRY(c, dalloc(&b.sgm_maps, 4 * N * g2));
+  HIP_TRY(c, dalloc(&b.sgm_S, N * (size_t)D2 * g2 * kSgmPaths));
+  b.sgm_D = D2; b.sgm_G = g2;
   return MOD_OK;
 }
 
@@ -585,19 +594,22 @@ int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, cons
   if (!left || !right) return MOD_SKIP_NO_DISPARITY_NOW;     // no image pair: no disparity (estimateDisparity fails, :272-276)
   if (!disparity) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null disparity plane");
   if ((rc = check_sgm_params(c, p))) return rc;
-  if ((rc = ensure_sgm_scratch(c, p->disparities))) return rc;
+  int group = 1;
+  if ((rc = ensure_sgm_scratch(c, p->disparities, frames, &group))) return rc;
   const int W = c->dc.W, H = c->dc.H, D = p->disparities;
   const size_t N = (size_t)W * H;
   Buffers &b = c->b;
-  uint32_t *cl = b.sgm_census, *cr = b.sgm_census + N;
-  uint8_t *dl = b.sgm_maps, *dr = dl + N, *dlm = dr + N, *drm = dlm + N;
   static const int order4[4] = {0, 1, 2, 3};
-  for (int f = 0; f < frames; f++) {
-    launch_sgm_census(W, H, 1, left + (size_t)f * N, cl, c->stream);
-    launch_sgm_census(W, H, 1, right + (size_t)f * N, cr, c->stream);
+  for (int f0 = 0; f0 < frames; f0 += group) {
+    const int g = std::min(group, frames - f0);
+    uint32_t *cl = b.sgm_census, *cr = b.sgm_census + N * g;
+    uint8_t *dl = b.sgm_maps, *dr = dl + N * g, *dlm = dr + N * g, *drm = dlm + N * g;
+    launch_sgm_census(W, H, g, left + (size_t)f0 * N, cl, c->stream);
+    launch_sgm_census(W, H, g, right + (size_t)f0 * N, cr, c->stream);
+    const size_t path_stride = N * (size_t)D * g;        // one volume [g][H][W][D] per path
     for (int i = 0; i < p->paths; i++)
-      launch_sgm_path(W, H, 1, D, p->p1, p->p2, p->paths == 4 ? order4[i] : i, cl, cr, nullptr, nullptr, b.sgm_S, i == 0, c->stream);
-    launch_sgm_finish(W, H, D, p->median, p->lr_check, b.sgm_S, dl, dr, dlm, drm, disparity + (size_t)f * N, c->stream);
+      launch_sgm_path(W, H, g, D, p->p1, p->p2, p->paths == 4 ? order4[i] : i, cl, cr, b.sgm_S + (size_t)i * path_stride, nullptr, nullptr, false, c->stream);
+    launch_sgm_finish(W, H, g, D, p->paths, path_stride, p->median, p->lr_check, b.sgm_S, dl, dr, dlm, drm, disparity + (size_t)f0 * N, c->stream);
   }
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;

@@ -135,18 +135,39 @@ __global__ __launch_bounds__(64) void k_sgm_path_line(int W, int H, int D, int P
   }
 }
 
-// Winner-take-all, one wave per pixel: left disparity = first minimum of S(x, .), right disparity = first minimum of S(x + d, d)
-// over the disparities with x + d < W.  Keys (S << 8 | d) make the DPP minimum pick the smallest d among equal sums.
-__global__ __launch_bounds__(64) void k_sgm_wta(int W, int H, int D, const uint16_t *__restrict__ S, uint8_t *__restrict__ dl,
-                                                uint8_t *__restrict__ dr) {
-  const int lane = threadIdx.x, x = blockIdx.x, y = blockIdx.y;
-  const size_t p = (size_t)y * W + x;
-  const int d0 = lane, d1 = lane + 64;
-  uint32_t kl = 0xffffffffu, kr = 0xffffffffu;
-  if (d0 < D) { kl = ((uint32_t)S[p * D + d0] << 8) | (uint32_t)d0; if (x + d0 < W) kr = ((uint32_t)S[(p + d0) * D + d0] << 8) | (uint32_t)d0; }
-  if (d1 < D) { kl = min(kl, ((uint32_t)S[p * D + d1] << 8) | (uint32_t)d1); if (x + d1 < W) kr = min(kr, ((uint32_t)S[(p + d1) * D + d1] << 8) | (uint32_t)d1); }
-  kl = wave_min_u32(kl); kr = wave_min_u32(kr);
-  if (lane == 0) { dl[p] = (uint8_t)(kl & 255u); dr[p] = (uint8_t)(kr & 255u); }
+// Winner-take-all over the sum of the path volumes, one workgroup (4 waves) per image row.  A wave takes every fourth pixel:
+// lane l owns disparities 2l and 2l + 1 (one 2-byte load per path volume), sums the paths, and
+//   left  disparity of x : first minimum of S(x, .)              -> DPP minimum over keys (S << 8 | d): the smallest d wins ties
+//   right disparity of x': first minimum of S(x' + d, d), x' + d < W -> the pixel x contributes its S(x, d) to x' = x - d with an LDS
+//                          atomicMin on the same keys (one row of keys in LDS): the cost volume is read ONCE, coalesced, instead of
+//                          gathering a diagonal per pixel
+__global__ __launch_bounds__(256) void k_sgm_wta(int W, int H, int D, int paths, size_t path_stride, const uint8_t *__restrict__ Lv,
+                                                 uint8_t *__restrict__ dl, uint8_t *__restrict__ dr) {
+  extern __shared__ uint32_t rkey[];                 // [W]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, y = blockIdx.x, f = blockIdx.y;
+  const size_t plane = (size_t)f * W * H;
+  Lv += plane * D; dl += plane; dr += plane;
+  for (int i = threadIdx.x; i < W; i += 256) rkey[i] = 0xffffffffu;
+  __syncthreads();
+  const int d0 = 2 * lane, d1 = d0 + 1;
+  for (int x = wv; x < W; x += 4) {
+    const size_t at = ((size_t)y * W + x) * D;
+    uint32_t s0 = 0, s1 = 0;
+    if (d0 < D) {
+      for (int p = 0; p < paths; p++) {
+        const uint8_t *q = Lv + (size_t)p * path_stride + at + d0;
+        if (d1 < D && !(D & 1)) { const uint32_t v = *reinterpret_cast<const uint16_t *>(q); s0 += v & 255u; s1 += v >> 8; }   // even D: 2-byte aligned
+        else { s0 += q[0]; if (d1 < D) s1 += q[1]; }
+      }
+    }
+    const uint32_t k0 = d0 < D ? ((s0 << 8) | (uint32_t)d0) : 0xffffffffu, k1 = d1 < D ? ((s1 << 8) | (uint32_t)d1) : 0xffffffffu;
+    const uint32_t kl = wave_min_u32(min(k0, k1));
+    if (lane == 0) dl[(size_t)y * W + x] = (uint8_t)(kl & 255u);
+    if (d0 < D && x - d0 >= 0) atomicMin(&rkey[x - d0], k0);
+    if (d1 < D && x - d1 >= 0) atomicMin(&rkey[x - d1], k1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < W; i += 256) dr[(size_t)y * W + i] = (uint8_t)(rkey[i] & 255u);
 }
 
 // 3 x 3 median of a uint8 map (border pixels keep their value): exact 9-element selection network
@@ -154,6 +175,7 @@ __device__ __forceinline__ void srt(int &a, int &b) { const int t = min(a, b); b
 __global__ __launch_bounds__(256) void k_sgm_median3(int W, int H, const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= W || y >= H) return;
+  in += (size_t)blockIdx.z * W * H; out += (size_t)blockIdx.z * W * H;
   const size_t p = (size_t)y * W + x;
   if (x == 0 || y == 0 || x == W - 1 || y == H - 1) { out[p] = in[p]; return; }
   int v0 = in[p - W - 1], v1 = in[p - W], v2 = in[p - W + 1], v3 = in[p - 1], v4 = in[p], v5 = in[p + 1], v6 = in[p + W - 1], v7 = in[p + W], v8 = in[p + W + 1];
@@ -167,6 +189,8 @@ __global__ __launch_bounds__(256) void k_sgm_lr(int W, int H, int lr_check, cons
                                                 float *__restrict__ disp) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= W || y >= H) return;
+  const size_t plane = (size_t)blockIdx.z * W * H;
+  dl += plane; dr += plane; disp += plane;
   const size_t p = (size_t)y * W + x;
   const int d = dl[p];
   bool ok = true;
@@ -197,10 +221,10 @@ void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direct
   }
 }
 
-void launch_sgm_finish(int W, int H, int D, int median, int lr_check, const uint16_t *S, uint8_t *dl, uint8_t *dr, uint8_t *dlm,
-                       uint8_t *drm, float *disparity, hipStream_t s) {
-  hipLaunchKernelGGL(k_sgm_wta, dim3(W, H), dim3(64), 0, s, W, H, D, S, dl, dr);
-  const dim3 g((W + 63) / 64, (H + 3) / 4), b(64, 4);
+void launch_sgm_finish(int W, int H, int frames, int D, int paths, size_t path_stride, int median, int lr_check, const uint8_t *Lv,
+                       uint8_t *dl, uint8_t *dr, uint8_t *dlm, uint8_t *drm, float *disparity, hipStream_t s) {
+  hipLaunchKernelGGL(k_sgm_wta, dim3(H, frames), dim3(256), (size_t)W * sizeof(uint32_t), s, W, H, D, paths, path_stride, Lv, dl, dr);
+  const dim3 g((W + 63) / 64, (H + 3) / 4, frames), b(64, 4);
   if (median) {
     hipLaunchKernelGGL(k_sgm_median3, g, b, 0, s, W, H, dl, dlm);
     hipLaunchKernelGGL(k_sgm_median3, g, b, 0, s, W, H, dr, drm);
