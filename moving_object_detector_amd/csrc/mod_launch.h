@@ -65,6 +65,6 @@ int ccl_request_capacity(int n);     // link requests one tile can emit at neigh
 // on-GPU disparity, first stages (sgm.hip)
 void launch_sgm_census(int W, int H, int frames, const uint8_t *img, uint32_t *out, hipStream_t s);
 void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direction, const uint32_t *cl, const uint32_t *cr,
-                     uint8_t *L, uint8_t *cost, uint16_t *S, bool first, hipStream_t s);
+                     uint8_t *L, uint8_t *cost, hipStream_t s);
 void launch_sgm_finish(int W, int H, int frames, int D, int paths, size_t path_stride, int median, int lr_check, const uint8_t *Lv,
                        uint8_t *dl, uint8_t *dr, uint8_t *dlm, uint8_t *drm, float *disparity, hipStream_t s);

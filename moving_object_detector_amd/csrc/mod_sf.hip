@@ -46,6 +46,10 @@ struct Buffers {
   uint8_t *sgm_maps = nullptr;
   uint8_t *sgm_S = nullptr;                 // [paths][group][H][W][D] path cost volumes
   int sgm_D = 0, sgm_G = 0;                 // disparities / frames per group the scratch is sized for
+  // the aggregation paths are independent of each other: they run side by side on these streams (forked from / joined to the
+  // context's stream with events), so that the waves of one path fill the SIMD slots another leaves idle
+  hipStream_t sgm_side[8] = {};
+  hipEvent_t sgm_fork[2] = {}, sgm_join[2][8] = {};
 };
 
 }  // namespace
@@ -395,6 +399,11 @@ void mod_destroy(ModContext *c) {
       for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     }
   }
+  for (hipStream_t q : c->b.sgm_side) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+  for (int k = 0; k < 2; k++) {
+    if (c->b.sgm_fork[k]) (void)hipEventDestroy(c->b.sgm_fork[k]);
+    for (hipEvent_t e : c->b.sgm_join[k]) if (e) (void)hipEventDestroy(e);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -546,7 +555,8 @@ static int check_sgm_params(ModContext *c, const ModSgmParams *p) {
   if (p->disparities < 1 || p->disparities > MOD_SGM_MAX_DISPARITIES) return fail(c, MOD_ERR_INVALID_ARGUMENT, "disparities must be in 1..128");
   if (p->p1 < 0 || p->p2 < p->p1 || 31 + p->p2 > 255) return fail(c, MOD_ERR_INVALID_ARGUMENT, "need 0 <= P1 <= P2 <= 224 (path costs are uint8)");
   if (p->paths != 4 && p->paths != 8) return fail(c, MOD_ERR_INVALID_ARGUMENT, "paths must be 4 or 8");
-  if ((size_t)c->dc.W * 8 > 64 * 1024) return fail(c, MOD_ERR_CAPACITY, "image row does not fit the census row buffer in LDS");
+  if (c->dc.W < 2) return fail(c, MOD_ERR_INVALID_ARGUMENT, "the disparity estimator needs images at least 2 pixels wide");
+  if ((size_t)c->dc.W * 8 + 4 > 64 * 1024) return fail(c, MOD_ERR_CAPACITY, "image row does not fit the census row buffer in LDS");
   return MOD_OK;
 }
 
@@ -558,32 +568,41 @@ int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left,
   if ((rc = check_sgm_params(c, p))) return rc;
   if (direction < 0 || direction > 7) return fail(c, MOD_ERR_INVALID_ARGUMENT, "direction must be 0..7");
   launch_sgm_path(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction, census_left, census_right, path_cost,
-                  matching_cost, nullptr, false, c->stream);
+                  matching_cost, c->stream);
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;
 }
 
 // scratch of the complete estimator for a GROUP of frames (one wave walks a path line, so a single frame cannot fill the GPU; the
 // frames of a group run side by side): per frame two census planes, one uint8 cost volume PER PATH (written once, never read
-// back by the path kernels: a running sum would put its load latency into every step of a path), four disparity maps
+// back by the path kernels: a running sum would put its load latency into every step of a path), four disparity maps.  Census
+// planes and volumes exist twice: consecutive groups overlap (mod_sgm_compute_dev).
 constexpr int kSgmGroup = 8, kSgmPaths = 8;
 constexpr size_t kSgmVolumeBudget = (size_t)24 << 30;    // bytes of cost volumes a context may hold
 
 static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
   Buffers &b = c->b;
   const size_t N = c->maxN;
-  int g = std::min(frames, kSgmGroup);
-  while (g > 1 && (size_t)g * N * D * kSgmPaths > kSgmVolumeBudget) g--;
+  const int even = (frames + kSgmGroup - 1) / kSgmGroup;          // groups of equal size: 11 frames go as 6 + 5, not 8 + 3
+  int g = (frames + even - 1) / even;
+  while (g > 1 && 2 * (size_t)g * N * D * kSgmPaths > kSgmVolumeBudget) g--;
   *group = g;
+  if (!b.sgm_fork[0]) {
+    for (int k = 0; k < 2; k++) {
+      HIP_TRY(c, hipEventCreateWithFlags(&b.sgm_fork[k], hipEventDisableTiming));
+      for (int i = 0; i < 8; i++) HIP_TRY(c, hipEventCreateWithFlags(&b.sgm_join[k][i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 8; i++) HIP_TRY(c, hipStreamCreateWithFlags(&b.sgm_side[i], hipStreamNonBlocking));
+  }
   if (b.sgm_S && b.sgm_D >= D && b.sgm_G >= g) return MOD_OK;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   void *old[] = {b.sgm_S, b.sgm_census, b.sgm_maps};
   for (void *q : old) if (q) HIP_TRY(c, hipFree(q));
   b.sgm_S = nullptr; b.sgm_census = nullptr; b.sgm_maps = nullptr; b.sgm_D = 0; b.sgm_G = 0;
   const int D2 = std::max(D, b.sgm_D), g2 = std::max(g, b.sgm_G);
-  HIP_TRY(c, dalloc(&b.sgm_census, 2 * N * g2));
+  HIP_TRY(c, dalloc(&b.sgm_census, 2 * 2 * N * g2));                       // two sets: see mod_sgm_compute_dev
   HIP_TRY(c, dalloc(&b.sgm_maps, 4 * N * g2));
-  HIP_TRY(c, dalloc(&b.sgm_S, N * (size_t)D2 * g2 * kSgmPaths));
+  HIP_TRY(c, dalloc(&b.sgm_S, 2 * N * (size_t)D2 * g2 * kSgmPaths));
   b.sgm_D = D2; b.sgm_G = g2;
   return MOD_OK;
 }
@@ -600,16 +619,37 @@ int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, cons
   const size_t N = (size_t)W * H;
   Buffers &b = c->b;
   static const int order4[4] = {0, 1, 2, 3};
-  for (int f0 = 0; f0 < frames; f0 += group) {
-    const int g = std::min(group, frames - f0);
-    uint32_t *cl = b.sgm_census, *cr = b.sgm_census + N * g;
-    uint8_t *dl = b.sgm_maps, *dr = dl + N * g, *dlm = dr + N * g, *drm = dlm + N * g;
+  // Groups of frames go through two sets of census planes and cost volumes: while the winner-take-all of group k streams its
+  // volumes (HBM-bound, context stream), the aggregation paths of group k + 1 (instruction-bound, one side stream per path) already
+  // run.  Order on the context stream: census(0) fork(0) | census(1) fork(1) join(0) finish(0) | census(2) fork(2) join(1) finish(1) ...
+  // — set s is written again (census(k + 2), paths(k + 2) behind fork(k + 2)) only after finish(k) has been enqueued before it.
+  const int ngroups = (frames + group - 1) / group;
+  const size_t set_census = 2 * N * group, set_volumes = N * (size_t)D * group * kSgmPaths;
+  uint8_t *dl = b.sgm_maps, *dr = dl + N * group, *dlm = dr + N * group, *drm = dlm + N * group;
+  auto start = [&](int k) {
+    const int f0 = k * group, g = std::min(group, frames - f0), s = k & 1;
+    uint32_t *cl = b.sgm_census + s * set_census, *cr = cl + N * g;
     launch_sgm_census(W, H, g, left + (size_t)f0 * N, cl, c->stream);
     launch_sgm_census(W, H, g, right + (size_t)f0 * N, cr, c->stream);
+    (void)hipEventRecord(b.sgm_fork[s], c->stream);
     const size_t path_stride = N * (size_t)D * g;        // one volume [g][H][W][D] per path
-    for (int i = 0; i < p->paths; i++)
-      launch_sgm_path(W, H, g, D, p->p1, p->p2, p->paths == 4 ? order4[i] : i, cl, cr, b.sgm_S + (size_t)i * path_stride, nullptr, nullptr, false, c->stream);
-    launch_sgm_finish(W, H, g, D, p->paths, path_stride, p->median, p->lr_check, b.sgm_S, dl, dr, dlm, drm, disparity + (size_t)f0 * N, c->stream);
+    for (int i = 0; i < p->paths; i++) {
+      (void)hipStreamWaitEvent(b.sgm_side[i], b.sgm_fork[s], 0);
+      launch_sgm_path(W, H, g, D, p->p1, p->p2, p->paths == 4 ? order4[i] : i, cl, cr, b.sgm_S + s * set_volumes + (size_t)i * path_stride,
+                      nullptr, b.sgm_side[i]);
+      (void)hipEventRecord(b.sgm_join[s][i], b.sgm_side[i]);
+    }
+  };
+  auto finish = [&](int k) {
+    const int f0 = k * group, g = std::min(group, frames - f0), s = k & 1;
+    for (int i = 0; i < p->paths; i++) (void)hipStreamWaitEvent(c->stream, b.sgm_join[s][i], 0);
+    launch_sgm_finish(W, H, g, D, p->paths, N * (size_t)D * g, p->median, p->lr_check, b.sgm_S + s * set_volumes, dl, dr, dlm, drm,
+                      disparity + (size_t)f0 * N, c->stream);
+  };
+  start(0);
+  for (int k = 0; k < ngroups; k++) {
+    if (k + 1 < ngroups) start(k + 1);
+    finish(k);
   }
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;

@@ -38,72 +38,152 @@ __global__ __launch_bounds__(256) void k_sgm_census(int W, int H, const uint8_t 
   out[fN + (size_t)y * W + x] = c;
 }
 
-// One horizontal aggregation path over one image row: ONE wave, lane l owns disparities l and l + 64; the row's census words sit
+// One horizontal aggregation path over one image row: ONE wave, lane l owns disparities 2l and 2l + 1; the row's census words sit
 // in LDS (the right word of disparity d at column x is word x - d: consecutive lanes read consecutive addresses), the previous
 // column's path costs in registers: neighbours d +- 1 come through DPP wave shifts, the minimum over d through a DPP reduction.
 //   L(x, d) = C(x, d) + min(L(xp, d), L(xp, d-1) + P1, L(xp, d+1) + P1, min_k L(xp, k) + P2) - min_k L(xp, k)
-// One step of a path for the lane's two disparities: previous path costs lp0 / lp1 (kNone where the disparity does not exist),
-// matching costs c0 / c1 -> new path costs.  All 64 lanes must be active.
-constexpr int kSgmNone = 1 << 20;                    // "no such disparity": larger than any cost + penalty
-__device__ __forceinline__ void sgm_step(int lp0, int lp1, int c0, int c1, int P1, int P2, int &l0, int &l1) {
-  const int m = (int)wave_min_u32((uint32_t)min(lp0, lp1));
-  // d - 1: lane - 1 (disparity 64's left neighbour is lane 63's first); d + 1: lane + 1 (disparity 63's right neighbour is lane 0's second)
-  const int lo63 = __builtin_amdgcn_readlane(lp0, 63), hi0 = __builtin_amdgcn_readlane(lp1, 0);
-  const int a0 = __builtin_amdgcn_update_dpp(kSgmNone, lp0, 0x138, 0xF, 0xF, false);     // wave_shr:1, lane 0 keeps kSgmNone
-  const int a1 = __builtin_amdgcn_update_dpp(lo63, lp1, 0x138, 0xF, 0xF, false);         // lane 0 <- lane 63's first
-  const int b0 = __builtin_amdgcn_update_dpp(hi0, lp0, 0x130, 0xF, 0xF, false);          // wave_shl:1, lane 63 <- lane 0's second
-  const int b1 = __builtin_amdgcn_update_dpp(kSgmNone, lp1, 0x130, 0xF, 0xF, false);
-  l0 = c0 + min(min(lp0, m + P2), min(a0, b0) + P1) - m;
-  l1 = c1 + min(min(lp1, m + P2), min(a1, b1) + P1) - m;
+// One step of a path for the lane's two disparities, held as a PACKED pair of 16-bit numbers (low half: disparity 2 * lane, high
+// half: disparity 2 * lane + 1; every quantity of the recurrence stays below 2^14): v_pk_min_u16 / v_pk_add_u16 do both at once,
+// the neighbours d - 1 / d + 1 are one DPP wave shift + one v_alignbit each, and the pair leaves as ONE 2-byte store.
+// `lp` previous path costs (kSgmNone where the disparity does not exist), `c` matching costs -> new path costs.  All 64 lanes active.
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kSgmNone = 0x3fffu;               // "no such disparity": larger than any cost + penalty, and twice it fits 16 bits
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b)); }
+// minimum over the wave's 128 packed costs: the two halves, then a DPP butterfly inside each row of 16 lanes, then the rows through
+// row_bcast (8 VALU instructions; the s_nop are the two wait states a DPP read of a just-written VGPR needs).  Wave-uniform (SGPR).
+__device__ __forceinline__ uint32_t sgm_min128(uint32_t lp) {
+  uint32_t v = min(lp & 0xffffu, lp >> 16);
+  asm("s_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// `prev` / `next` are the DPP shift registers, carried from step to step: a wave shift leaves the lane without a source (lane 0 /
+// lane 63) untouched, so those lanes keep the kSgmNone they were initialised with and no constant is re-materialised per step.
+struct SgmShift { uint32_t prev, next; };
+__device__ __forceinline__ SgmShift sgm_shift_init() { return SgmShift{kSgmNone << 16, kSgmNone}; }
+__device__ __forceinline__ uint32_t sgm_step(uint32_t lp, uint32_t c, uint32_t p1pk, uint32_t p2, SgmShift &sh) {
+  const uint32_t m = sgm_min128(lp);                                  // min over all disparities
+  const uint32_t mpk = m | (m << 16), mp2pk = (m + p2) | ((m + p2) << 16);   // scalar unit
+  // d - 1: (high half of lane - 1, own low half); d + 1: (own high half, low half of lane + 1); the ends see kSgmNone
+  sh.prev = (uint32_t)__builtin_amdgcn_update_dpp((int)sh.prev, (int)lp, 0x138, 0xF, 0xF, false);   // wave_shr:1
+  sh.next = (uint32_t)__builtin_amdgcn_update_dpp((int)sh.next, (int)lp, 0x130, 0xF, 0xF, false);   // wave_shl:1
+  const uint32_t a = __builtin_amdgcn_alignbit(lp, sh.prev, 16), b = __builtin_amdgcn_alignbit(sh.next, lp, 16);
+  const uint32_t best = pk_min(pk_min(lp, mp2pk), pk_add(pk_min(a, b), p1pk));
+  return pk_sub(pk_add(c, best), mpk);
+}
+// A wave-uniform GLOBAL pointer the compiler must keep in SGPRs, so that loads / stores take the "SGPR base + 32-bit lane offset"
+// form instead of a 64-bit add per lane (the readfirstlane is a no-op on a value that is already scalar; it stops the optimiser
+// from re-associating the lane offset into the base).
+#define SGM_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ SGM_GLOBAL uint8_t *sgm_uniform(const void *p) {
+  const uint64_t v = (uint64_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (SGM_GLOBAL uint8_t *)(((uint64_t)hi << 32) | lo);
 }
 
-// where a path's costs go: its own volume (stage tests), the matching cost, and / or the running sum over the paths
+// where a path's costs go: the path's volume, and (stage tests) the matching cost
 struct SgmOut {
-  uint8_t *L, *C;       // [H][W][D] or null
-  uint16_t *S;          // [H][W][D] or null
-  int first;            // S = l instead of S += l (first path of a frame)
+  uint8_t *L, *C;       // [H][W][D]; C may be null
 };
-__device__ __forceinline__ void sgm_emit(const SgmOut &o, size_t at, int d, int l, int c) {
-  if (o.L) o.L[at + d] = (uint8_t)l;
-  if (o.C) o.C[at + d] = (uint8_t)c;
-  if (o.S) o.S[at + d] = (uint16_t)(o.first ? l : (int)o.S[at + d] + l);
+// lanes whose disparities do not exist (d >= D) keep kSgmNone in that half and store nothing
+struct SgmLane {
+  uint32_t keep, none;  // masks: halves that exist / kSgmNone in the halves that do not
+  bool has0, has1;
+};
+__device__ __forceinline__ SgmLane sgm_lane(int lane, int D) {
+  SgmLane s;
+  s.has0 = 2 * lane < D; s.has1 = 2 * lane + 1 < D;
+  s.keep = (s.has0 ? 0xffffu : 0u) | (s.has1 ? 0xffff0000u : 0u);
+  s.none = (s.has0 ? 0u : kSgmNone) | (s.has1 ? 0u : (kSgmNone << 16));
+  return s;
+}
+// FULL: D == 128, every lane owns two disparities: one unconditional 2-byte store at (wave-uniform pixel base) + 2 * lane
+template <bool FULL>
+__device__ __forceinline__ void sgm_emit(const SgmOut &o, const SgmLane &ln, size_t at, uint32_t lane, uint32_t l, uint32_t c, bool even_d, uint32_t sel) {
+  SGM_GLOBAL uint8_t *pl = sgm_uniform(o.L + at), *pc = o.C ? sgm_uniform(o.C + at) : nullptr;
+  const uint32_t q = 2 * lane;
+  if (FULL || (ln.has1 && even_d)) {                                  // both disparities exist and the pair is 2-byte aligned
+    *(SGM_GLOBAL uint16_t *)(pl + q) = (uint16_t)__builtin_amdgcn_perm(0u, l, sel);
+    if (pc) *(SGM_GLOBAL uint16_t *)(pc + q) = (uint16_t)__builtin_amdgcn_perm(0u, c, sel);
+  } else {
+    if (ln.has0) { pl[q] = (uint8_t)(l & 0xffu); if (pc) pc[q] = (uint8_t)(c & 0xffu); }
+    if (ln.has1) { pl[q + 1] = (uint8_t)((l >> 16) & 0xffu); if (pc) pc[q + 1] = (uint8_t)((c >> 16) & 0xffu); }
+  }
 }
 
-template <bool RTL>
+// The right census words of a lane's two disparities are neighbours in memory: word x - d1 (d1 = 2 lane + 1) and the one after it
+// (x - d0).  They are read as ONE pair at max(x - d1, 0) — never left of the row (a saturating subtraction) — so near the left
+// border (x < d1) the pair is (word 0, word 1) and the masked branch below picks word 0 for d0 == x.  Needs W >= 2.
+struct SgmPair { uint32_t a, b; };
+// matching costs of the lane's two disparities at column x (31 where the disparity leaves the right image); dlast = D - 1
+__device__ __forceinline__ uint32_t sgm_cost_pk(uint32_t wl, SgmPair r, int x, int d0, int dlast) {
+  uint32_t c = (uint32_t)__popc(wl ^ r.b) + ((uint32_t)__popc(wl ^ r.a) << 16);
+  if (x < dlast) {                                                    // wave-uniform: only the first D - 1 columns
+    asm volatile("" ::: "memory");                                    // keep this a branch: the other columns skip it
+    const uint32_t c0 = x > d0 ? (c & 0xffffu) : x == d0 ? (c >> 16) : 31u;
+    const uint32_t c1 = x > d0 ? (c >> 16) : 31u;
+    c = c0 | (c1 << 16);
+  }
+  return c;
+}
+
+template <bool RTL, bool FULL>
 __global__ __launch_bounds__(64) void k_sgm_path_h(int W, int H, int D, int P1, int P2, const uint32_t *__restrict__ cl,
                                                    const uint32_t *__restrict__ cr, SgmOut out) {
-  extern __shared__ uint32_t srow[];                 // [W] left census row, [W] right census row
+  extern __shared__ uint32_t srow[];                 // [W + 1] right census row, [W] left census row
   const int lane = threadIdx.x, y = blockIdx.x, f = blockIdx.y;
   const size_t row = ((size_t)f * H + y) * W;
-  for (int i = lane; i < W; i += 64) { srow[i] = cl[row + i]; srow[W + i] = cr[row + i]; }
+  uint32_t *sr = srow, *sl = srow + W + 1;
+  for (int i = lane; i < W; i += 64) { sl[i] = cl[row + i]; sr[i] = cr[row + i]; }
+  if (lane == 0) sr[W] = 0;                          // W == 1: the pair read at x = 0
   __syncthreads();
-  const int d0 = lane, d1 = lane + 64;
-  const bool has0 = d0 < D, has1 = d1 < D;
-  constexpr int kNone = kSgmNone;
-  int lp0 = kNone, lp1 = kNone;
+  const int d0 = 2 * lane, d1 = 2 * lane + 1, dlast = D - 1;
+  const bool even_d = !(D & 1);
+  const SgmLane ln = sgm_lane(lane, D);
+  const uint32_t p1pk = (uint32_t)P1 | ((uint32_t)P1 << 16);
+  uint32_t sel = 0x0c0c0200u;                        // v_perm selector "bytes 0 and 2", pinned to an SGPR outside the loop
+  asm volatile("" : "+s"(sel));
   const size_t vol = (size_t)f * H * W * D;
-  if (out.L) out.L += vol;
+  out.L += vol;
   if (out.C) out.C += vol;
-  if (out.S) out.S += vol;
+  uint32_t lp = kSgmNone | (kSgmNone << 16);
+  // the census words of a step are read one step ahead, unconditionally: their LDS latency hides behind the recurrence of the
+  // step before
+  auto pair = [&](int xx) { const uint32_t i = __builtin_elementwise_sub_sat((uint32_t)xx, (uint32_t)d1); SgmPair r; r.a = sr[i]; r.b = sr[i + 1]; return r; };
+  SgmShift sh = sgm_shift_init();
+  int x = RTL ? W - 1 : 0;
+  uint32_t wl = sl[x];
+  SgmPair r = pair(x);
   for (int step = 0; step < W; step++) {
-    const int x = RTL ? W - 1 - step : step;
-    const uint32_t wl = srow[x];
-    const int c0 = x - d0 >= 0 ? __popc(wl ^ srow[W + max(x - d0, 0)]) : 31;
-    const int c1 = x - d1 >= 0 ? __popc(wl ^ srow[W + max(x - d1, 0)]) : 31;
-    int l0 = c0, l1 = c1;
-    if (step > 0) sgm_step(lp0, lp1, c0, c1, P1, P2, l0, l1);
-    const size_t o = ((size_t)y * W + x) * D;
-    if (has0) sgm_emit(out, o, d0, l0, c0);
-    if (has1) sgm_emit(out, o, d1, l1, c1);
-    lp0 = has0 ? l0 : kNone;
-    lp1 = has1 ? l1 : kNone;
+    const int xn = min(max(RTL ? x - 1 : x + 1, 0), W - 1);
+    const uint32_t wln = sl[xn];
+    const SgmPair rn = pair(xn);
+    const uint32_t c = sgm_cost_pk(wl, r, x, d0, dlast);
+    uint32_t l = step > 0 ? sgm_step(lp, c, p1pk, (uint32_t)P2, sh) : c;
+    if (!FULL) l = (l & ln.keep) | ln.none;
+    sgm_emit<FULL>(out, ln, ((size_t)y * W + x) * D, lane, l, c, even_d, sel);
+    lp = l;
+    x = RTL ? x - 1 : x + 1;
+    wl = wln; r = rn;
   }
 }
 
 // Vertical and diagonal paths: one wave per path LINE (direction (RX, RY), RY != 0).  Lines enter through the first row in path
 // order (W of them) and, for the diagonals, through the first column in path order (H - 1 more).  Census words come straight from
-// HBM / L2 (the right word of disparity d at (x, y) is word (x - d, y): lanes read a descending run of addresses).
-template <int RX, int RY>
+// L2 / HBM (one 8-byte load per lane, see SgmPair), kPF steps ahead of their use: the recurrence is a dependent chain per step, a
+// memory round trip per step would dominate it.
+constexpr int kSgmPF = 4;
+template <int RX, int RY, bool FULL>
 __global__ __launch_bounds__(64) void k_sgm_path_line(int W, int H, int D, int P1, int P2, const uint32_t *__restrict__ cl,
                                                       const uint32_t *__restrict__ cr, SgmOut out) {
   const int lane = threadIdx.x, line = blockIdx.x, f = blockIdx.y;
@@ -112,26 +192,44 @@ __global__ __launch_bounds__(64) void k_sgm_path_line(int W, int H, int D, int P
   else { x = RX > 0 ? 0 : W - 1; y = RY > 0 ? line - W + 1 : H - 2 - (line - W); }   // the entry row's own pixel is a row line
   const size_t plane = (size_t)f * H * W, vol = plane * D;
   cl += plane; cr += plane;
-  if (out.L) out.L += vol;
+  out.L += vol;
   if (out.C) out.C += vol;
-  if (out.S) out.S += vol;
-  const int d0 = lane, d1 = lane + 64;
-  const bool has0 = d0 < D, has1 = d1 < D;
-  int lp0 = kSgmNone, lp1 = kSgmNone;
-  bool first = true;
-  while (x >= 0 && x < W && y >= 0 && y < H) {       // wave-uniform
-    const size_t p = (size_t)y * W + x;
-    const uint32_t wl = cl[p];
-    const int c0 = x - d0 >= 0 ? __popc(wl ^ cr[p - min(d0, x)]) : 31;
-    const int c1 = x - d1 >= 0 ? __popc(wl ^ cr[p - min(d1, x)]) : 31;
-    int l0 = c0, l1 = c1;
-    if (!first) sgm_step(lp0, lp1, c0, c1, P1, P2, l0, l1);
-    if (has0) sgm_emit(out, p * D, d0, l0, c0);
-    if (has1) sgm_emit(out, p * D, d1, l1, c1);
-    lp0 = has0 ? l0 : kSgmNone;
-    lp1 = has1 ? l1 : kSgmNone;
-    first = false;
-    x += RX; y += RY;
+  const int d0 = 2 * lane, d1 = 2 * lane + 1, dlast = D - 1;
+  const bool even_d = !(D & 1);
+  const SgmLane ln = sgm_lane(lane, D);
+  const uint32_t p1pk = (uint32_t)P1 | ((uint32_t)P1 << 16);
+  uint32_t sel = 0x0c0c0200u;                        // v_perm selector "bytes 0 and 2", pinned to an SGPR outside the loop
+  asm volatile("" : "+s"(sel));
+  // number of pixels on the line
+  int len = RY > 0 ? H - y : y + 1;
+  if (RX > 0) len = min(len, W - x);
+  if (RX < 0) len = min(len, x + 1);
+  auto fetch = [&](int i, uint32_t &wl, SgmPair &r) {                  // census words of the line's i-th pixel (clamped to the line)
+    const int k = min(i, len - 1), xx = x + RX * k, yy = y + RY * k;
+    const size_t rowp = (size_t)yy * W;
+    wl = cl[rowp + xx];
+    const SGM_GLOBAL uint32_t *q = (const SGM_GLOBAL uint32_t *)(sgm_uniform(cr + rowp) + 4u * __builtin_elementwise_sub_sat((uint32_t)xx, (uint32_t)d1));
+    r.a = q[0]; r.b = q[1];
+  };
+  uint32_t wl[kSgmPF];
+  SgmPair r[kSgmPF];
+#pragma unroll
+  for (int i = 0; i < kSgmPF; i++) fetch(i, wl[i], r[i]);
+  uint32_t lp = kSgmNone | (kSgmNone << 16);
+  SgmShift sh = sgm_shift_init();
+  for (int i0 = 0; i0 < len; i0 += kSgmPF) {         // wave-uniform
+#pragma unroll
+    for (int u = 0; u < kSgmPF; u++) {
+      const int i = i0 + u;
+      if (i >= len) break;                           // wave-uniform
+      const int xx = x + RX * i, yy = y + RY * i;
+      const uint32_t c = sgm_cost_pk(wl[u], r[u], xx, d0, dlast);
+      fetch(i + kSgmPF, wl[u], r[u]);                // slot u is free again: the words of pixel i + kPF
+      uint32_t l = i > 0 ? sgm_step(lp, c, p1pk, (uint32_t)P2, sh) : c;
+      if (!FULL) l = (l & ln.keep) | ln.none;
+      sgm_emit<FULL>(out, ln, ((size_t)yy * W + xx) * D, lane, l, c, even_d, sel);
+      lp = l;
+    }
   }
 }
 
@@ -165,6 +263,58 @@ __global__ __launch_bounds__(256) void k_sgm_wta(int W, int H, int D, int paths,
     if (lane == 0) dl[(size_t)y * W + x] = (uint8_t)(kl & 255u);
     if (d0 < D && x - d0 >= 0) atomicMin(&rkey[x - d0], k0);
     if (d1 < D && x - d1 >= 0) atomicMin(&rkey[x - d1], k1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < W; i += 256) dr[(size_t)y * W + i] = (uint8_t)(rkey[i] & 255u);
+}
+
+// The same for disparity counts that are multiples of 16 (the default 128 is): lane = (pixel of the wave's group of 8, 16 consecutive
+// disparities) — one 16-byte load per path and lane, a wave reads 1 KB contiguous per path; the path costs are summed as packed pairs
+// of 16-bit numbers (sums stay below 8 x 128), the minimum over a pixel's 8 lanes is three DPP steps.
+__global__ __launch_bounds__(256) void k_sgm_wta16(int W, int H, int D, int paths, size_t path_stride, const uint8_t *__restrict__ Lv,
+                                                   uint8_t *__restrict__ dl, uint8_t *__restrict__ dr) {
+  extern __shared__ uint32_t rkey[];                 // [W]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, y = blockIdx.x, f = blockIdx.y;
+  const size_t plane = (size_t)f * W * H;
+  Lv += plane * D; dl += plane; dr += plane;
+  for (int i = threadIdx.x; i < W; i += 256) rkey[i] = 0xffffffffu;
+  __syncthreads();
+  const int sub = lane & 7, px = lane >> 3, dbase = sub * 16;
+  const bool has = dbase < D;                        // D / 16 lanes of a pixel carry disparities
+  for (int x0 = wv * 8; x0 < W; x0 += 32) {
+    const int x = x0 + px;
+    const bool live = has && x < W;
+    uint32_t e[4] = {0, 0, 0, 0}, o[4] = {0, 0, 0, 0};          // packed sums: e[j] = (byte 0 | byte 2 << 16) of word j, o[j] = (byte 1 | byte 3 << 16)
+    if (live) {
+      const uint8_t *q = Lv + ((size_t)y * W + x) * D + dbase;
+      for (int p = 0; p < paths; p++) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(q + (size_t)p * path_stride);
+        e[0] += w.x & 0x00ff00ffu; o[0] += (w.x >> 8) & 0x00ff00ffu;
+        e[1] += w.y & 0x00ff00ffu; o[1] += (w.y >> 8) & 0x00ff00ffu;
+        e[2] += w.z & 0x00ff00ffu; o[2] += (w.z >> 8) & 0x00ff00ffu;
+        e[3] += w.w & 0x00ff00ffu; o[3] += (w.w >> 8) & 0x00ff00ffu;
+      }
+    }
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t d = (uint32_t)(dbase + 4 * j);
+      const uint32_t k0 = ((e[j] & 0xffffu) << 8) | d, k1 = ((o[j] & 0xffffu) << 8) | (d + 1), k2 = ((e[j] >> 16) << 8) | (d + 2), k3 = ((o[j] >> 16) << 8) | (d + 3);
+      if (live) {
+        best = min(best, min(min(k0, k1), min(k2, k3)));
+        const int xr = x - (int)d;
+        if (xr >= 0) atomicMin(&rkey[xr], k0);
+        if (xr >= 1) atomicMin(&rkey[xr - 1], k1);
+        if (xr >= 2) atomicMin(&rkey[xr - 2], k2);
+        if (xr >= 3) atomicMin(&rkey[xr - 3], k3);
+      }
+    }
+    // minimum over the 8 lanes of the pixel: quad swaps, then the mirror of the half row (lanes 0..7 <-> 7..0)
+    uint32_t t;
+    t = MOD_DPP(best, 0xB1); best = min(best, t);
+    t = MOD_DPP(best, 0x4E); best = min(best, t);
+    t = MOD_DPP(best, 0x141); best = min(best, t);
+    if (sub == 0 && x < W) dl[(size_t)y * W + x] = (uint8_t)(best & 255u);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < W; i += 256) dr[(size_t)y * W + i] = (uint8_t)(rkey[i] & 255u);
@@ -205,25 +355,30 @@ void launch_sgm_census(int W, int H, int frames, const uint8_t *img, uint32_t *o
 }
 
 void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direction, const uint32_t *cl, const uint32_t *cr,
-                     uint8_t *L, uint8_t *cost, uint16_t *S, bool first, hipStream_t s) {
-  SgmOut o{L, cost, S, first ? 1 : 0};
-  const size_t lds = (size_t)2 * W * sizeof(uint32_t);
+                     uint8_t *L, uint8_t *cost, hipStream_t s) {
+  SgmOut o{L, cost};
+  const size_t lds = ((size_t)2 * W + 1) * sizeof(uint32_t);
   const dim3 b(64);
-  switch (direction) {   // numbering of oracle/sgm_ref.cpp: 0 (+1,0) 1 (-1,0) 2 (0,+1) 3 (0,-1) 4 (+1,+1) 5 (-1,-1) 6 (-1,+1) 7 (+1,-1)
-    case 0: hipLaunchKernelGGL(k_sgm_path_h<false>, dim3(H, frames), b, lds, s, W, H, D, P1, P2, cl, cr, o); break;
-    case 1: hipLaunchKernelGGL(k_sgm_path_h<true>, dim3(H, frames), b, lds, s, W, H, D, P1, P2, cl, cr, o); break;
-    case 2: hipLaunchKernelGGL((k_sgm_path_line<0, 1>), dim3(W, frames), b, 0, s, W, H, D, P1, P2, cl, cr, o); break;
-    case 3: hipLaunchKernelGGL((k_sgm_path_line<0, -1>), dim3(W, frames), b, 0, s, W, H, D, P1, P2, cl, cr, o); break;
-    case 4: hipLaunchKernelGGL((k_sgm_path_line<1, 1>), dim3(W + H - 1, frames), b, 0, s, W, H, D, P1, P2, cl, cr, o); break;
-    case 5: hipLaunchKernelGGL((k_sgm_path_line<-1, -1>), dim3(W + H - 1, frames), b, 0, s, W, H, D, P1, P2, cl, cr, o); break;
-    case 6: hipLaunchKernelGGL((k_sgm_path_line<-1, 1>), dim3(W + H - 1, frames), b, 0, s, W, H, D, P1, P2, cl, cr, o); break;
-    default: hipLaunchKernelGGL((k_sgm_path_line<1, -1>), dim3(W + H - 1, frames), b, 0, s, W, H, D, P1, P2, cl, cr, o); break;
+  const dim3 gh(H, frames), gv(W, frames), gd(W + H - 1, frames);
+#define SGM_PATH(FULL)                                                                                                              \
+  switch (direction) { /* numbering of oracle/sgm_ref.cpp: 0 (+1,0) 1 (-1,0) 2 (0,+1) 3 (0,-1) 4 (+1,+1) 5 (-1,-1) 6 (-1,+1) 7 (+1,-1) */ \
+    case 0: hipLaunchKernelGGL((k_sgm_path_h<false, FULL>), gh, b, lds, s, W, H, D, P1, P2, cl, cr, o); break;                      \
+    case 1: hipLaunchKernelGGL((k_sgm_path_h<true, FULL>), gh, b, lds, s, W, H, D, P1, P2, cl, cr, o); break;                       \
+    case 2: hipLaunchKernelGGL((k_sgm_path_line<0, 1, FULL>), gv, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                      \
+    case 3: hipLaunchKernelGGL((k_sgm_path_line<0, -1, FULL>), gv, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                     \
+    case 4: hipLaunchKernelGGL((k_sgm_path_line<1, 1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                      \
+    case 5: hipLaunchKernelGGL((k_sgm_path_line<-1, -1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                    \
+    case 6: hipLaunchKernelGGL((k_sgm_path_line<-1, 1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                     \
+    default: hipLaunchKernelGGL((k_sgm_path_line<1, -1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                    \
   }
+  if (D == 128) { SGM_PATH(true) } else { SGM_PATH(false) }
+#undef SGM_PATH
 }
 
 void launch_sgm_finish(int W, int H, int frames, int D, int paths, size_t path_stride, int median, int lr_check, const uint8_t *Lv,
                        uint8_t *dl, uint8_t *dr, uint8_t *dlm, uint8_t *drm, float *disparity, hipStream_t s) {
-  hipLaunchKernelGGL(k_sgm_wta, dim3(H, frames), dim3(256), (size_t)W * sizeof(uint32_t), s, W, H, D, paths, path_stride, Lv, dl, dr);
+  if (D % 16 == 0) hipLaunchKernelGGL(k_sgm_wta16, dim3(H, frames), dim3(256), (size_t)W * sizeof(uint32_t), s, W, H, D, paths, path_stride, Lv, dl, dr);
+  else hipLaunchKernelGGL(k_sgm_wta, dim3(H, frames), dim3(256), (size_t)W * sizeof(uint32_t), s, W, H, D, paths, path_stride, Lv, dl, dr);
   const dim3 g((W + 63) / 64, (H + 3) / 4, frames), b(64, 4);
   if (median) {
     hipLaunchKernelGGL(k_sgm_median3, g, b, 0, s, W, H, dl, dlm);

@@ -103,7 +103,8 @@ def _compute(ctx, left, right, **kw):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("W,H,D,F,seed", [(320, 240, 128, 2, 1), (131, 77, 64, 1, 2), (70, 9, 128, 1, 3), (9, 7, 8, 1, 5), (96, 40, 33, 11, 6)])
+@pytest.mark.parametrize("W,H,D,F,seed", [(320, 240, 128, 2, 1), (131, 77, 64, 1, 2), (70, 9, 128, 1, 3), (9, 7, 8, 1, 5), (96, 40, 33, 11, 6),
+                                          (64, 24, 16, 20, 8)])     # 20 frames: three groups, so a volume set is used twice
 def test_complete_estimator_matches_the_oracle(W, H, D, F, seed):
     from oracle import pysgm
     from oracle import sgm_numpy as sn

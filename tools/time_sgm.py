@@ -7,7 +7,7 @@ from moving_object_detector_amd import capi, synth
 from moving_object_detector_amd.pipeline import Context
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1280, 720)
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-F = 16
+F = int(os.environ.get("SGM_F", "16"))
 pairs = [synth.make_stereo_images(W, H, 7 + f, D, n_boxes=5) for f in range(F)]
 ctx = Context(W, H, max_frames=F)
 ctx.set_camera(synth.make_camera(W, H)); ctx.set_params(synth.Params())
