@@ -43,7 +43,7 @@ extern "C" {
 
 typedef struct ModContext ModContext;
 
-#define MOD_MAX_WIDTH 16384   /* the tied-median replay keeps one count per image column of a cluster in LDS */
+#define MOD_MAX_WIDTH 16384   /* widest image a context accepts (one image row of census words must fit LDS; tested up to 8256) */
 
 /* Context creation parameters. */
 typedef struct ModConfig {
@@ -128,7 +128,9 @@ typedef struct ModSceneFlowPlanes {
 
 /* Output of the clusterer (clusterer_nodelet.cpp:85-95,324-343). Device pointers. */
 typedef struct ModClusterOut {
-  int32_t   *labels;      /* [frames][H][W]: -1 = none, 0..K-1 in the reference's order (removeSmallClusters, :354-393) */
+  int32_t   *labels;      /* optional [frames][H][W]: -1 = none, 0..K-1 in the reference's order (removeSmallClusters, :354-393).
+                             The reference renders its cluster image only while somebody subscribes to it
+                             (publishClustersImage, :235-236,292-322): pass NULL and the 4 B/px plane is never written. */
   ModObject *objects;     /* [frames][max_objects] */
   int32_t   *n_objects;   /* [frames] accepted objects (publishMovingObjects, :324-343) */
   int32_t   *n_clusters;  /* [frames] K = clusters surviving the size filter (may be NULL) */

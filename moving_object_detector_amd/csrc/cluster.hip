@@ -692,7 +692,8 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
 }
 
 // Final labels + member compaction, one workgroup per tile.  labels[p] = new label of p's component or -1 (the whole
-// plane is written here, 4 B/px).  A pixel's parent entry names its tile root, so the few tile roots resolve their final
+// plane is written here, 4 B/px, when the caller asks for it: the reference renders its cluster image only for subscribers,
+// clusterer_nodelet.cpp:235-236).  A pixel's parent entry names its tile root, so the few tile roots resolve their final
 // root's new label once (into LDS) and every pixel just looks it up; members of surviving clusters are counted per tile
 // root in LDS, one cursor atomic per (tile root) reserves their slots, then (||v|| bits, pixel) records are appended.
 // XY_FROM_Z: the planes come from the fused scene-flow kernel of the same call (mod_process_dev), where every valid pixel has
@@ -710,8 +711,10 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   const size_t fN = (size_t)f * N;
   const int x0 = wi * 64, y0 = blockIdx.y * TH, r0 = w * RPW, x = x0 + lane;
   if (a.tilehdr[tidx * 2] == 0) {                    // nothing dynamic in the tile
+    if (a.labels) {
 #pragma unroll
-    for (int j = 0; j < RPW; j++) { const int y = y0 + r0 + j; if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = -1; }
+      for (int j = 0; j < RPW; j++) { const int y = y0 + r0 + j; if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = -1; }
+    }
     return;
   }
   // ---- all row-independent HBM reads up front (clamped addresses, results of non-dynamic lanes are ignored) ----
@@ -755,7 +758,7 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
     int l = dyn ? nlmap[cl] : -1;
     if (!MOD_CHECK(a, l >= -1 && l < a.max_objects, 7)) l = -1;
     nl[j] = l; cell[j] = cl; rank[j] = 0;
-    if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = l;
+    if (a.labels && y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = l;
     any_member = any_member || (__ballot(l >= 0) != 0);
   }
   // ---- members: counted per tile root in LDS ----
@@ -1091,7 +1094,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
 // not after it, so ranks from two prefix counts give every swap at once — and the finished (<= 16 element) range gets the
 // stable insertion sort.  Rare path: one workgroup per flagged cluster, nothing to do for the others.
 // Scratch (all dead by now): keys -> parent plane, pixels -> rsize plane, swap lists -> the member arrays.
-constexpr int kTieThreads = 1024, kTieCols = 16384, kTieLds = 8192;   // kTieCols: 2 * kTieLds counts, one per column at the least
+constexpr int kTieThreads = 1024, kTieLds = 8192;
 
 struct TieShared {           // control block of one workgroup of k_median_ties
   int cntA[kTieThreads / 64], cntB[kTieThreads / 64];
@@ -1275,133 +1278,75 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
     // one column x 64 rows; pass A sets bit (row & 63) of a member's cell, a prefix over the cells in column-major order gives
     // every cell its first slot, pass B puts member (column, row) at slot = start[cell] + popcount(mask[cell] below its bit).
     const int nseg64 = (ymax - ymin + 64) / 64;
-    if (ncols * nseg64 <= kTieLds) {
-      const int ncell = ncols * nseg64;
+    {
+      // Boxes with more than kTieLds cells (one tied cluster across most of a large image) go through the same two passes once
+      // per run of kTieLds cells in column-major order; `base` carries the members of the runs before.  (Round 1 scanned the
+      // labels plane for such boxes; the member list needs neither that plane nor the velocities again.)
+      const int ncell = ncols * nseg64;              // < 2^21 + W: W * H < 2^27
       const float invWf = 1.0f / (float)c.W;
-      for (int i = tid; i < kTieLds; i += kTieThreads) cmask[i] = 0ull;
-      __syncthreads();
       auto cell_of = [&](uint32_t p, int &bit) {
         const uint32_t y = (N < (1u << 24)) ? (uint32_t)(((float)p + 0.5f) * invWf) : p / (uint32_t)c.W, x = p - y * (uint32_t)c.W;
         const int ry = (int)y - ymin;
         bit = ry & 63;
         return ((int)x - xmin) * nseg64 + (ry >> 6);
       };
-      for (int i0 = tid; i0 < size; i0 += kTieThreads * 8) {
-        uint32_t p8[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) p8[u] = Bpos[min(i0 + u * kTieThreads, size - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (i0 + u * kTieThreads < size) { int bit; const int cl = cell_of(p8[u], bit); atomicOr((unsigned long long *)&cmask[cl], 1ull << bit); }
-      }
-      __syncthreads();
-      TSTAMP(21)
-      {   // exclusive prefix of the cell populations; thread t owns cells 8t .. 8t+7
-        int cnt[8], tot = 0;
-#pragma unroll
-        for (int u = 0; u < 8; u++) { const int ci2 = tid * 8 + u; cnt[u] = ci2 < ncell ? __popcll((unsigned long long)cmask[ci2]) : 0; tot += cnt[u]; }
-        int incl = tot;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        if (lane == 63) sh.cntA[wv] = incl;
+      int base = 0;
+      for (int g0 = 0; g0 < ncell; g0 += kTieLds) {  // block-uniform
+        const int ncl = min(kTieLds, ncell - g0);
+        for (int i = tid; i < kTieLds; i += kTieThreads) cmask[i] = 0ull;
         __syncthreads();
-        if (tid == 0) { int run = 0; for (int t = 0; t < kTieThreads / 64; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; } }
-        __syncthreads();
-        int run = sh.cntA[wv] + incl - tot;
+        for (int i0 = tid; i0 < size; i0 += kTieThreads * 8) {
+          uint32_t p8[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { cstart[tid * 8 + u] = (uint32_t)run; run += cnt[u]; }
-      }
-      __syncthreads();
-      for (int i0 = tid; i0 < size; i0 += kTieThreads * 8) {
-        uint32_t p8[8], k8[8];
+          for (int u = 0; u < 8; u++) p8[u] = Bpos[min(i0 + u * kTieThreads, size - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = min(i0 + u * kTieThreads, size - 1); p8[u] = Bpos[i]; k8[u] = Apos[i]; }
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (i0 + u * kTieThreads < size) {
-            int bit;
-            const int cl = cell_of(p8[u], bit);
-            const int slot = (int)cstart[cl] + __popcll((unsigned long long)(cmask[cl] & ((1ull << bit) - 1ull)));
-            if (MOD_CHECK(a, cl >= 0 && cl < ncell && slot >= 0 && slot < size, 11)) {
-              key[slot] = k8[u];                      // ||v|| bits as k_final computed them (norm3_f32)
-              val[slot] = p8[u];
+          for (int u = 0; u < 8; u++)
+            if (i0 + u * kTieThreads < size) {
+              int bit;
+              const int cl = cell_of(p8[u], bit) - g0;
+              if (cl >= 0 && cl < ncl) atomicOr((unsigned long long *)&cmask[cl], 1ull << bit);
             }
-          }
-      }
-      __syncthreads();
-      TSTAMP(22)
-    } else {
-    // Fallback for bounding boxes with more than kTieLds cells: scan the box in the image.
-    if (ncols > kTieCols) { (void)MOD_CHECK(a, false, 14); continue; }   // cannot happen: mod_create rejects images wider than MOD_MAX_WIDTH = kTieCols
-    // ---- members in column-major order: count, prefix, fill.  The bounding box is cut into (64-column chunk, row segment)
-    // work items so that all 16 waves are busy; a wave reads 4 rows of its chunk at a time (coalesced, 4-16 reads in flight).
-    // Counts live in the LDS arrays of the later LDS phase: cc[segment][column] ----
-    const int *lab = a.labels + fN;
-    const int nchunks = (ncols + 63) / 64, ncp = nchunks * 64;
-    const int nseg = max(1, min(8, (2 * kTieLds) / ncp));          // lkey + lval hold 2 * kTieLds ints
-    const int rows = ymax - ymin + 1, segH = (rows + nseg - 1) / nseg;
-    int *cc = (int *)lkey;
-    int *cc2 = (int *)lval;
-    auto CC = [&](int sg, int cx) -> int & { const int i = sg * ncp + cx; return i < kTieLds ? cc[i] : cc2[i - kTieLds]; };
-    for (int it = wv; it < nchunks * nseg; it += kTieThreads / 64) {
-      const int ch = it % nchunks, sg = it / nchunks;
-      const int cx = ch * 64 + lane, x = min(xmin + cx, c.W - 1);
-      const int ya = ymin + sg * segH, yb = min(ya + segH - 1, ymax);
-      int cnt = 0;
-      for (int y0 = ya; y0 <= yb; y0 += 8) {
-        int l8[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) l8[u] = lab[(size_t)min(y0 + u, yb) * c.W + x];
-#pragma unroll
-        for (int u = 0; u < 8; u++) cnt += (y0 + u <= yb) && l8[u] == k;
-      }
-      CC(sg, cx) = (cx < ncols) ? cnt : 0;
-    }
-    __syncthreads();
-    TSTAMP(21)
-    if (MOD_ABLATE(c, 1 << 21)) continue;
-    // exclusive prefix in column-major order: columns left to right, inside a column the segments top to bottom.
-    // Thread t owns the cpt consecutive columns t * cpt ... (cpt = 2 up to 2048 columns, at most kTieCols / kTieThreads = 16)
-    {
-      const int cpt = max(2, (ncp + kTieThreads - 1) / kTieThreads), cbeg = tid * cpt;
-      int tot = 0;
-      for (int u = 0; u < cpt; u++) { const int cx = cbeg + u; if (cx < ncp) for (int sg = 0; sg < nseg; sg++) tot += CC(sg, cx); }
-      int incl = tot;
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-      if (lane == 63) sh.cntA[wv] = incl;
-      __syncthreads();
-      if (tid == 0) { int run = 0; for (int t = 0; t < kTieThreads / 64; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; } }
-      __syncthreads();
-      int start = sh.cntA[wv] + incl - tot;
-      for (int u = 0; u < cpt; u++) {
-        const int cx = cbeg + u;
-        if (cx < ncp) for (int sg = 0; sg < nseg; sg++) { const int t = CC(sg, cx); CC(sg, cx) = start; start += t; }
-      }
-    }
-    __syncthreads();
-    for (int it = wv; it < nchunks * nseg; it += kTieThreads / 64) {
-      const int ch = it % nchunks, sg = it / nchunks;
-      const int cx = ch * 64 + lane, x = min(xmin + cx, c.W - 1);
-      const int ya = ymin + sg * segH, yb = min(ya + segH - 1, ymax);
-      int slot = CC(sg, cx);
-      for (int y0 = ya; y0 <= yb; y0 += 8) {          // labels and velocities of 8 rows in flight, all coalesced
-        int l8[8];
-        float vx[8], vy[8], vz[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const size_t q = (size_t)min(y0 + u, yb) * c.W + x;
-          l8[u] = lab[q]; vx[u] = a.vx[fN + q]; vy[u] = a.vy[fN + q]; vz[u] = a.vz[fN + q];
         }
+        __syncthreads();
+        TSTAMP(21)
+        {   // exclusive prefix of the cell populations; thread t owns cells 8t .. 8t+7
+          int cnt[8], tot = 0;
 #pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (cx < ncols && y0 + u <= yb && l8[u] == k) {
-            val[slot] = (uint32_t)((y0 + u) * c.W + x);
-            key[slot] = __float_as_uint(norm3_f32(vx[u], vy[u], vz[u]));
-            slot++;
-          }
+          for (int u = 0; u < 8; u++) { const int ci2 = tid * 8 + u; cnt[u] = ci2 < ncl ? __popcll((unsigned long long)cmask[ci2]) : 0; tot += cnt[u]; }
+          int incl = tot;
+          for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+          if (lane == 63) sh.cntA[wv] = incl;
+          __syncthreads();
+          if (tid == 0) { int run = base; for (int t = 0; t < kTieThreads / 64; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; } sh.cntB[0] = run; }
+          __syncthreads();
+          int run = sh.cntA[wv] + incl - tot;
+#pragma unroll
+          for (int u = 0; u < 8; u++) { cstart[tid * 8 + u] = (uint32_t)run; run += cnt[u]; }
+          base = sh.cntB[0];
+        }
+        __syncthreads();
+        for (int i0 = tid; i0 < size; i0 += kTieThreads * 8) {
+          uint32_t p8[8], k8[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) { const int i = min(i0 + u * kTieThreads, size - 1); p8[u] = Bpos[i]; k8[u] = Apos[i]; }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (i0 + u * kTieThreads < size) {
+              int bit;
+              const int cl = cell_of(p8[u], bit) - g0;
+              if (cl >= 0 && cl < ncl) {
+                const int slot = (int)cstart[cl] + __popcll((unsigned long long)(cmask[cl] & ((1ull << bit) - 1ull)));
+                if (MOD_CHECK(a, slot >= 0 && slot < size, 11)) {
+                  key[slot] = k8[u];                    // ||v|| bits as k_final computed them (norm3_f32)
+                  val[slot] = p8[u];
+                }
+              }
+            }
+        }
+        __syncthreads();
+        TSTAMP(22)
       }
-    }
-    __syncthreads();
-    TSTAMP(22)
+      (void)MOD_CHECK(a, base == size, 14);          // every member lies in exactly one cell
     }
     TSTAMP(23)
     if (MOD_ABLATE(c, 1 << 22)) continue;

@@ -280,8 +280,8 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
                 const ModClusterOut *out) {
   if (!pl || !pl->x || !pl->y || !pl->z || !pl->vx || !pl->vy || !pl->vz)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster input planes x,y,z,vx,vy,vz are required");
-  if (!out || !out->labels || !out->objects || !out->n_objects)
-    return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster outputs labels, objects, n_objects are required");
+  if (!out || !out->objects || !out->n_objects)
+    return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster outputs objects, n_objects are required");
   ClArgs a;
   a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
   a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.mpix;
@@ -736,7 +736,7 @@ int mod_process_frame_host(ModContext *c, const float *disparity_now, const floa
   staged_planes(c, &pl);
   pl.cloud_aos = cloud_aos ? b.h_aos : nullptr;
   ModClusterOut out{};
-  out.labels = b.h_labels; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
+  out.labels = labels ? b.h_labels : nullptr; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
   rc = mod_process_dev(c, &in, &pl, &out);
   if (rc) return rc;
   if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, b.h_aos, 32 * N, hipMemcpyDeviceToHost, c->stream));
@@ -778,7 +778,7 @@ int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int3
   rc = mod_unpack_cloud_dev(c, 1, b.h_aos, &pl);
   if (rc) return rc;
   ModClusterOut out{};
-  out.labels = b.h_labels; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
+  out.labels = labels ? b.h_labels : nullptr; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
   rc = mod_cluster_dev(c, 1, &pl, &out);
   if (rc) return rc;
   return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
@@ -845,7 +845,7 @@ int mod_submit_frame_host(ModContext *c, const float *disparity_now, const float
   pl.x = q; pl.y = q + N; pl.z = q + 2 * N; pl.vx = q + 3 * N; pl.vy = q + 4 * N; pl.vz = q + 5 * N;
   pl.cloud_aos = cloud_aos ? p.aos[slot] : nullptr;
   ModClusterOut out{};
-  out.labels = p.labels[slot]; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
+  out.labels = labels ? p.labels[slot] : nullptr; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
   if ((rc = mod_process_dev(c, &in, &pl, &out))) return rc;
   HIP_TRY(c, hipEventRecord(p.ev_done[slot], c->stream));
   // results: their own stream

@@ -77,16 +77,17 @@ class Context:
             pass
 
     # ---- buffers ----------------------------------------------------------------------------------------------
-    def workspace(self, frames: int, aos: bool = False, extras: bool = False) -> dict:
-        """Output buffers for `frames` frames, allocated once and reused."""
-        key = (frames, self.height, self.width, aos, extras)
+    def workspace(self, frames: int, aos: bool = False, extras: bool = False, labels: bool = True) -> dict:
+        """Output buffers for `frames` frames, allocated once and reused.  labels=False: no cluster-label plane (the reference
+        renders its cluster image only for subscribers, clusterer_nodelet.cpp:235-236)."""
+        key = (frames, self.height, self.width, aos, extras, labels)
         if self._ws is not None and self._ws["key"] == key:
             return self._ws
         H, W, dev = self.height, self.width, self.device
         ws = {"key": key}
         ws["planes"] = torch.empty((6, frames, H, W), dtype=torch.float32, device=dev)
         ws["mask"] = torch.empty((frames, H, self.mask_words), dtype=torch.int64, device=dev)
-        ws["labels"] = torch.empty((frames, H, W), dtype=torch.int32, device=dev)
+        ws["labels"] = torch.empty((frames, H, W), dtype=torch.int32, device=dev) if labels else None
         ws["objects"] = torch.zeros((frames, self.max_objects, capi.MOD_OBJECT_BYTES), dtype=torch.uint8, device=dev)
         ws["n_objects"] = torch.zeros((frames,), dtype=torch.int32, device=dev)
         ws["n_clusters"] = torch.zeros((frames,), dtype=torch.int32, device=dev)
@@ -109,7 +110,7 @@ class Context:
 
     @staticmethod
     def _cluster_struct(ws) -> capi.ModClusterOut:
-        return capi.ModClusterOut(ws["labels"].data_ptr(), ws["objects"].data_ptr(), ws["n_objects"].data_ptr(),
+        return capi.ModClusterOut(ws["labels"].data_ptr() if ws["labels"] is not None else None, ws["objects"].data_ptr(), ws["n_objects"].data_ptr(),
                                   ws["n_clusters"].data_ptr())
 
     def make_batch(self, d_now: torch.Tensor, d_prev: Optional[torch.Tensor], flow: Optional[torch.Tensor], ts, qs, dts):

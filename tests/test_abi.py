@@ -60,7 +60,7 @@ def test_config_limits_are_checked_before_any_device_work():
     for cfg in (capi.ModConfig(0, 64, 48, 70000, 0, 0, None),        # frames ride in grid.y / grid.z
                 capi.ModConfig(0, 16384, 8192, 1, 0, 0, None),       # 2^27 px: 32-bit byte offsets of the AoS cloud
                 capi.ModConfig(0, 64, 48, 65535, 40000, 0, None),    # frame * max_objects + cluster must fit 31 bits
-                capi.ModConfig(0, 16385, 16, 1, 0, 0, None),         # wider than MOD_MAX_WIDTH (tied-median column table)
+                capi.ModConfig(0, 16385, 16, 1, 0, 0, None),         # wider than MOD_MAX_WIDTH
                 capi.ModConfig(0, 0, 48, 1, 0, 0, None)):
         assert lib.mod_create(C.byref(cfg), C.byref(h)) == capi.MOD_ERR_INVALID_ARGUMENT
         assert not h.value

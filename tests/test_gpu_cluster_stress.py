@@ -25,6 +25,17 @@ def _cluster_gpu(planes, prm, W, H):
     assert ctx.cluster(1, ws, mask_ready=False) == 0
     ctx.synchronize()
     out = ws["labels"][0].cpu().numpy(), ctx.objects_to_host(ws)[0], int(ws["n_clusters"][0])
+    # the same cloud without a labels plane (the reference renders its cluster image only for subscribers): identical objects
+    raw, n_obj = ws["objects"][0].cpu().numpy().copy(), int(ws["n_objects"][0])
+    ws2 = ctx.workspace(1, labels=False)
+    assert ws2["labels"] is None
+    for i, k in enumerate(PLANES):
+        ws2["planes"][i, 0].copy_(torch.from_numpy(planes[k]))
+    ws2["objects"].zero_()
+    assert ctx.cluster(1, ws2, mask_ready=False) == 0
+    ctx.synchronize()
+    assert int(ws2["n_objects"][0]) == n_obj and int(ws2["n_clusters"][0]) == out[2]
+    assert np.array_equal(ws2["objects"][0].cpu().numpy()[:n_obj], raw[:n_obj]), "objects differ without the labels plane"
     ctx.close()
     return out
 

@@ -69,6 +69,13 @@ def test_host_entry_points_match_golden(path):
     n2 = C.c_int32(-1)
     rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W, H, 32, 32 * W, labels2.ctypes.data, objs.ctypes.data, 64, C.byref(n2))
     assert rc == 0 and np.array_equal(labels2, g["labels"]) and n2.value == n.value
+    # without a labels plane (no subscriber of the cluster image, clusterer_nodelet.cpp:235-236): the same objects
+    objs3, n3 = np.zeros(64, OBJECT_DTYPE), C.c_int32(-1)
+    rc = ctx.lib.mod_process_frame_host(ctx.h, g["d_now"].ctypes.data, g["d_prev"].ctypes.data, g["flow"].ctypes.data, tf,
+                                        float(np.asarray(g["dt"]).item()), None, None, objs3.ctypes.data, 64, C.byref(n3))
+    assert rc == 0 and n3.value == n.value and objs3[: n3.value].tobytes() == objs[: n.value].tobytes()
+    rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W, H, 32, 32 * W, None, objs3.ctypes.data, 64, C.byref(n3))
+    assert rc == 0 and n3.value == n.value and objs3[: n3.value].tobytes() == objs[: n.value].tobytes()
     # a cloud of the wrong size is an error, not a silent skip
     rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W - 1, H, 32, 32 * W, labels2.ctypes.data, objs.ctypes.data, 64, C.byref(n2))
     assert rc == capi.MOD_ERR_INVALID_ARGUMENT and b"cloud size" in ctx.lib.mod_last_error(ctx.h)

@@ -50,8 +50,8 @@ def test_tied_median_matches_std_sort(oracle, case):
 
 @pytest.mark.parametrize("W,H", [(8256, 8), (2304, 260)])
 def test_tied_median_of_a_very_wide_cluster(oracle, W, H):
-    """A flagged cluster whose bounding box has more than 8192 (column x 64-row) cells takes k_median_ties' image-scan layout; its
-    column table covers up to MOD_MAX_WIDTH = 16384 columns (round 1 gave up beyond 2048 and kept the canonical pick)."""
+    """A flagged cluster whose bounding box has more than 8192 (column x 64-row) cells: k_median_ties lays its members out in
+    several runs of 8192 cells (round 1 scanned the labels plane and gave up beyond 2048 columns, keeping the canonical pick)."""
     from moving_object_detector_amd import synth
     from test_gpu_cluster_stress import _cluster_gpu
     rng = np.random.default_rng(W)

@@ -50,6 +50,28 @@ for d in sorted(glob.glob(f"{src}/pmc_sq*")):
             if m: agg[(m.group(1), r["Counter_Name"])][0] += 1; agg[(m.group(1), r["Counter_Name"])][1] += float(r["Counter_Value"])
     for (k, cn), (n, v) in agg.items(): sq[k][cn] = v / n
 json.dump({"other_bench_lines": extra, "sq_counters_per_64_frame_dispatch": sq}, open(f"profiles/{tag}_extra.json", "w"), indent=1)
+# on-GPU disparity: timings, config-5 lines, per-kernel averages and SQ counters (per dispatch of one group of 8 frames)
+sgm = {"timings": [], "config5": {}, "kernels_avg_us": {}, "sq_counters_per_dispatch": {}}
+for name in ("sgm_720.log", "sgm_1080.log"):
+    try: sgm["timings"] += [l.strip() for l in open(f"{src}/{name}") if "paths=" in l]
+    except Exception as e: sgm["timings"].append(f"{name}: {e}")
+for name in ("config5_1080", "config5_720"):
+    try: sgm["config5"][name] = json.loads(open(f"{src}/{name}.json").read().strip().splitlines()[-1])
+    except Exception as e: sgm["config5"][name] = {"error": str(e)}
+try:
+    st = max(glob.glob(f"{src}/sgm_stats/*/*_kernel_stats.csv"), key=os.path.getmtime)
+    for r in csv.DictReader(open(st)):
+        m = re.search(r"(k_sgm_\w+(<[^>]*>)?)", r["Name"])
+        if m: sgm["kernels_avg_us"][m.group(1)] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "percent": float(r["Percentage"])}
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for fcsv in glob.glob(f"{src}/sgm_pmc/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(fcsv)):
+            m = re.search(r"(k_sgm_\w+(<[^>]*>)?)", r["Kernel_Name"])
+            if m: agg[(m.group(1), r["Counter_Name"])][0] += 1; agg[(m.group(1), r["Counter_Name"])][1] += float(r["Counter_Value"])
+    for (k, cn), (n, v) in agg.items(): sgm["sq_counters_per_dispatch"].setdefault(k, {})[cn] = v / n
+except Exception as e:
+    sgm["error"] = str(e)
+json.dump(sgm, open(f"profiles/{tag}_sgm.json", "w"), indent=1)
 print("value", bench["value"], "pairs/s;", bench["roofline"]["kernel"], "frac", round(bench["roofline"]["frac"], 3))
 for r in rows:
     if float(r["Percentage"]) > 0.3: print("%-62s calls %4s avg_us %9.2f %6s%%" % (r["Name"][:62], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))

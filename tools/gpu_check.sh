@@ -12,4 +12,5 @@ if [ "$soak" != "0" ]; then
 fi
 python bench.py --no-cpu-baseline > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || { tail -5 gpurun_out/${tag}_bench.err; exit 1; }
 python bench.py --workload pairs --no-cpu-baseline > gpurun_out/${tag}_bench_pairs.json 2> gpurun_out/${tag}_bench_pairs.err || { tail -5 gpurun_out/${tag}_bench_pairs.err; exit 1; }
-python tools/bench_summary.py gpurun_out/${tag}_bench.json gpurun_out/${tag}_bench_pairs.json
+python bench.py --no-labels --no-cpu-baseline > gpurun_out/${tag}_bench_nolabels.json 2> gpurun_out/${tag}_bench_nolabels.err || { tail -5 gpurun_out/${tag}_bench_nolabels.err; exit 1; }
+python tools/bench_summary.py gpurun_out/${tag}_bench.json gpurun_out/${tag}_bench_pairs.json gpurun_out/${tag}_bench_nolabels.json

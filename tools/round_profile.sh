@@ -22,4 +22,15 @@ for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_WAVE_C
   timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc_sq$i -- python3 $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --frames 64 > $out/pmc_sq$i.json 2> $out/pmc_sq$i.err
   echo "sq$i rc=$?"
 done
+# on-GPU disparity: timings, config-5 end-to-end lines, kernel trace and SQ counters of tools/time_sgm.py
+cd $repo
+timeout -k 10 200 python3 tools/time_sgm.py > $out/sgm_720.log 2> /dev/null
+SGM_F=10 timeout -k 10 200 python3 tools/time_sgm.py 1920 1080 > $out/sgm_1080.log 2> /dev/null
+timeout -k 10 300 python3 tools/bench_config5.py > $out/config5_1080.json 2> $out/config5.err
+timeout -k 10 300 python3 tools/bench_config5.py --width 1280 --height 720 > $out/config5_720.json 2>> $out/config5.err
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/sgm_stats -- python3 $repo/tools/time_sgm.py > /dev/null 2> $out/sgm_stats.err
+echo "sgm stats rc=$?"
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/sgm_pmc -- python3 $repo/tools/time_sgm.py > /dev/null 2> $out/sgm_pmc.err
+echo "sgm pmc rc=$?"
 ls $out
