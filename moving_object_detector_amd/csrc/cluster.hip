@@ -75,7 +75,7 @@ __device__ __forceinline__ void wave_accumulate(int *sizes, int *keys, int strid
   uint64_t todo = __ballot(rec_idx >= 0);
   while (todo) {
     const int leader = __ffsll((unsigned long long)todo) - 1;
-    const int lid = __shfl(rec_idx, leader);
+    const int lid = __builtin_amdgcn_readlane(rec_idx, leader);
     const bool mine = rec_idx == lid;
     const uint64_t grp = __ballot(mine);
     const uint32_t k = wave_min_u32(mine ? key : (uint32_t)kKeyNone);
@@ -125,7 +125,7 @@ __device__ __forceinline__ int lds_find_compress(int *L, int a) {
 }
 __device__ __forceinline__ void wave_unite_lds(int *L, bool need, int &cur, int &last, int other, int lane) {
   if (__ballot(need) == 0) return;
-  const int pc = __shfl_up(cur, 1), po = __shfl_up(other, 1), pn = __shfl_up((int)need, 1);
+  const int pc = wave_prev_i32(cur), po = wave_prev_i32(other), pn = wave_prev_i32((int)need);
   const bool rep = need && !(lane > 0 && pn && pc == cur && po == other);
   if (rep) lds_unite(L, cur, other);
   if (need) { last = other; cur = lds_find_compress(L, cur); }
@@ -217,6 +217,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
   lds_barrier();
   STAMP(0)
+  if (MOD_ABLATE(c, 1 << 14)) return;                // (ablation builds: kernel truncated after a phase, timing only — tools/ablate.sh)
   // ---- phase A1: horizontal runs of the wave's rows by ballot (no atomics) ---------------------------------------------
   // One row of the grid: runs of the 64 tile columns by ballot; the left-halo cells chained to lane 0 by horizontal links
   // (h0 - lane 0, h1 - h0, ...) join lane 0's run.  Returns "linked to the left neighbour" (an up-left edge).
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint64_t mw = m0[gr], ml = mL[gr];
     const bool dyn = (mw >> lane) & 1ull;
     const float z = zt[me];
-    const float zl = __shfl_up(z, 1);
+    const float zl = wave_prev_f32(z);
     const bool cl = dyn && lane > 0 && ((mw >> (lane - 1)) & 1ull) && !(fabsf(z - zl) > th);   // linked to the left neighbour
     const uint64_t C = __ballot(cl);
     const uint64_t starts = mw & ~C;                // run starts: dynamic and not linked to the left
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   for (int hr = NMAX - 1 - w; hr >= NMAX - n; hr -= NW)   // the halo rows above the tile, dealt to the waves like the tile rows
     if (m0[hr] | mL[hr]) link_row(hr);                    // wave-uniform
   lds_barrier();
+  if (MOD_ABLATE(c, 1 << 15)) return;
   // ---- phase A2: vertical pre-link (the pixel straight above), one union per distinct (run, run-above) pair -----------
   auto link_up = [&](int gr) -> bool {              // grid row gr with grid row gr - 1 (tile rows and halo rows alike)
     const int me = gr * PW + NMAX + lane;
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   }
   for (int hr = NMAX - 1 - w; hr > NMAX - n; hr -= NW) link_up(hr);
   lds_barrier();
+  if (MOD_ABLATE(c, 1 << 16)) return;
   // ---- phase A3: flatten, so that phase B can compare labels directly -------------------------------------------------
   auto flatten_row = [&](int gr) {
     const int me = gr * PW + NMAX + lane;
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   for (int hr = NMAX - 1 - w; hr >= NMAX - n; hr -= NW) flatten_row(hr);
   lds_barrier();
   STAMP(1)
+  if (MOD_ABLATE(c, 1 << 17)) return;
   // ---- phase B: the rest of the up-left window --------------------------------------------------------------------------
   const uint32_t kmask = (2u << n) - 1u;              // n + 1 low bits
 #pragma unroll
@@ -337,8 +341,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       if (dv == 0) nb &= ~(1u << n);                 // k == 0 is p itself
       if (__ballot(nb != 0) == 0) continue;          // wave-uniform
       COUNT(9, 1)
+      if (MOD_ABLATE(c, 8192)) continue;             // (ablation builds: loop header only)
       const int base = qg * PW + NMAX + lane;
-      if (same) {                                    // only pixels that still lack their first up-left edge look for it
+      if (same) {
+        if (MOD_ABLATE(c, 4096)) continue;                                    // only pixels that still lack their first up-left edge look for it
         if (__ballot(!up & (nb != 0)) == 0) continue;
         uint32_t cand2 = __brev(nb) >> (31 - n);
         if (dv == 0) cand2 &= ~3u;
@@ -421,6 +427,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     if (lane == 0 && gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + wi] = rb;
   }
   STAMP(5)
+  if (MOD_ABLATE(c, 1 << 18)) return;
   // halo pixels that ended up in a tile component belong to other tiles, whose roots are not known yet: leave one link
   // request (halo pixel, tile root) per connected group of them for k_ccl_link.  First every halo cell is flattened to its root
   // (no union runs any more), so that the neighbour tests below are plain LDS reads.
@@ -479,7 +486,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       if (lb) {
         int base = 0;
         if (lane == 0) base = atomicAdd(&s_nreq, __popcll((unsigned long long)lb));
-        base = __shfl(base, 0);
+        base = __builtin_amdgcn_readfirstlane(base);
         if (linked) {
           const int slot = base + __popcll((unsigned long long)(lb & ((1ull << lane) - 1ull)));
           if (MOD_CHECK(a, slot >= 0 && slot < a.req_cap, 12) && MOD_CHECK(a, rg >= 0 && (size_t)rg < N && hg >= 0 && (size_t)hg < N, 13))
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_
       if (MOD_CHECK(a, (size_t)q.x < N && (size_t)q.y < N, 0)) { ra = parent[q.x]; rb = (int)q.y; }
       if (!MOD_CHECK(a, ra < 0 || ((size_t)ra < N && rb >= 0), 1)) ra = -1;
     }
-    const int pa = __shfl_up(ra, 1), pb = __shfl_up(rb, 1);
+    const int pa = wave_prev_i32(ra), pb = wave_prev_i32(rb);
     if (ra >= 0 && !(lane > 0 && pa == ra && pb == rb)) uf_unite(parent, ra, rb);
   }
 }
@@ -770,12 +777,12 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
       if (mb == 0) continue;                         // wave-uniform
       // lanes that share the first member's tile root reserve ranks with one LDS atomic; stragglers use their own
       const int lead = __ffsll((unsigned long long)mb) - 1;
-      const int c0 = __shfl(cl, lead);
+      const int c0 = __builtin_amdgcn_readlane(cl, lead);
       const bool grp = l >= 0 && cl == c0;
       const uint64_t gb = __ballot(grp);
       int base = 0;
       if (lane == lead) base = atomicAdd(&lcount[c0], __popcll((unsigned long long)gb));
-      base = __shfl(base, lead);
+      base = __builtin_amdgcn_readlane(base, lead);
       if (grp) rank[j] = base + __popcll((unsigned long long)(gb & ((1ull << lane) - 1ull)));
       else if (l >= 0) rank[j] = atomicAdd(&lcount[cl], 1);
     }

@@ -95,6 +95,10 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 // Wave-wide min/max: four DPP steps reduce each row of 16 lanes (quad swaps, half-row mirror, row mirror), four
 // v_readlane + scalar ops combine the rows.  All 64 lanes must be active.  ~11 instructions, no LDS traffic.
 #define MOD_DPP(v, ctrl) (uint32_t) __builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, 0xF, 0xF, false)
+// value of the lane below (lane 0 keeps its own): one DPP move instead of __shfl_up's ds_bpermute, which is an LDS-pipeline
+// round trip.  All 64 lanes must be active.
+__device__ __forceinline__ int wave_prev_i32(int v) { return (int)MOD_DPP(v, 0x138); }                    // wave_shr:1
+__device__ __forceinline__ float wave_prev_f32(float v) { return __uint_as_float(MOD_DPP(__float_as_uint(v), 0x138)); }
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   uint32_t t;
   t = MOD_DPP(v, 0xB1); v = t < v ? t : v;     // quad_perm [1,0,3,2]

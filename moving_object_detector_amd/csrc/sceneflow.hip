@@ -173,11 +173,13 @@ __device__ __forceinline__ void sf_pixel(const DevCam &c, const FrameConst &fc, 
 
 // OR-combine the 4-bit nibbles of 16 consecutive lanes into one 64-bit word (lane 16k -> word k of the wave).
 __device__ __forceinline__ uint64_t nibbles_to_word(uint32_t nib, int lane) {
+  // DPP moves (quad swaps, then the mirror inside each group of 8: after two steps the four lanes of a quad agree, so the mirror
+  // brings in the other quad), not __shfl's ds_bpermute — those are LDS-pipeline round trips
   uint32_t v = nib << (4 * (lane & 7));
-  v |= __shfl_xor(v, 1);
-  v |= __shfl_xor(v, 2);
-  v |= __shfl_xor(v, 4);
-  const uint32_t hi = __shfl_down(v, 8);
+  v |= MOD_DPP(v, 0xB1);                             // quad_perm [1,0,3,2]
+  v |= MOD_DPP(v, 0x4E);                             // quad_perm [2,3,0,1]
+  v |= MOD_DPP(v, 0x141);                            // row_half_mirror
+  const uint32_t hi = MOD_DPP(v, 0x108);             // row_shl:8: lane 16k reads lane 16k + 8
   return (uint64_t)v | ((uint64_t)hi << 32);
 }
 
