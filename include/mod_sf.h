@@ -194,8 +194,10 @@ typedef struct ModSgmParams {
   int32_t lr_check;      /* left-right consistency check, tolerance 1 */
   int32_t median;        /* 3 x 3 median of the winner-take-all maps */
 } ModSgmParams;
-/* computeDisparity: device images in, device disparity plane out (enqueued on the context's stream; scratch — per frame of a group
- * of up to 8 frames one W*H*disparities uint8 cost volume per path — is allocated on first use).  NULL image -> MOD_SKIP_NO_DISPARITY_NOW, as a failed estimateDisparity. */
+/* computeDisparity: device images in, device disparity plane out.  Ordered like any other work on the context's stream (the
+ * aggregation paths run on streams of the context's own, forked from and joined to it with events).  Scratch — two sets of, per
+ * frame of a group of up to 8 frames, one W*H*disparities uint8 cost volume per path, at most 24 GB — is allocated on first use.
+ * Images at least 2 pixels wide.  NULL image -> MOD_SKIP_NO_DISPARITY_NOW, as a failed estimateDisparity. */
 int  mod_sgm_compute_dev(ModContext *ctx, int32_t frames, const uint8_t *left, const uint8_t *right, const ModSgmParams *params,
                          float *disparity);
 /* the same for one frame in host memory (what a ROS node holding sensor_msgs/Image buffers calls); synchronous */
