@@ -1439,9 +1439,8 @@ void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t 
   const int tiles = (int)(g.x * g.y), per_block = 4 * (64 / kTileH);
   hipLaunchKernelGGL(k_ccl_merge<kTileH>, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles);
 }
-void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  // the second ClusterInfo array (rank scratch) lives right behind the first one
-  ClusterInfo *tmp = a.clusters + (size_t)frames * a.max_objects;
+void launch_select(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *tmp, hipStream_t s) {
+  // tmp: rank scratch, [frames][max_objects] like a.clusters
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
 }
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {

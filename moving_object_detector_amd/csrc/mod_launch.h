@@ -56,7 +56,7 @@ void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
 void launch_tile_flags(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);   // tile headers from a mask plane
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
-void launch_select(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
+void launch_select(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *rank_scratch, hipStream_t s);
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 int ccl_tile_rows();                 // tile height of k_ccl_tile

@@ -291,6 +291,7 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
   a.xy_from_z = flags_ready ? 1 : 0;                  // only mod_process_dev's fused path hands over its own scene-flow planes
   a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
+  ClusterInfo *const rank_scratch = c->b.clusters + (size_t)c->cfg.max_frames * c->max_objects;   // second half of the allocation
   {
     StageTimer t(c, MOD_STAGE_CCL_TILE);
     if (!mask_ready) launch_dynamic_mask(c->dc, frames, pl->vx, pl->vy, pl->vz, (uint64_t *)mask, c->stream);
@@ -300,7 +301,7 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   }
   { StageTimer t(c, MOD_STAGE_CCL_LINK); launch_ccl_link(c->dc, a, frames, c->stream); }
   { StageTimer t(c, MOD_STAGE_CCL_MERGE); launch_ccl_merge(c->dc, a, frames, c->stream); }
-  { StageTimer t(c, MOD_STAGE_SELECT); launch_select(c->dc, a, frames, c->stream); }
+  { StageTimer t(c, MOD_STAGE_SELECT); launch_select(c->dc, a, frames, rank_scratch, c->stream); }
   { StageTimer t(c, MOD_STAGE_FINAL); launch_final(c->dc, a, frames, c->stream); }
   { StageTimer t(c, MOD_STAGE_MEDIAN); launch_median(c->dc, a, frames, c->stream); }
   HIP_TRY(c, hipGetLastError());
