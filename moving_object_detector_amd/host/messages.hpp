@@ -50,6 +50,9 @@ struct DisparityImage {
 // sensor_msgs/CameraInfo: only the projection matrix P is used (image_geometry::PinholeCameraModel::fromCameraInfo)
 struct CameraInfo { int width = 0, height = 0; double P[12] = {0}; };
 
+// sensor_msgs/Image, encoding mono8 (what the disparity estimator consumes): row-major, step == width
+struct Image { Header header; int width = 0, height = 0; const uint8_t *data = nullptr; };
+
 // cv_bridge::CvImage with encoding 32FC2: optical flow, x then y
 struct FlowImage { Header header; int width = 0, height = 0; const float *data = nullptr; };
 

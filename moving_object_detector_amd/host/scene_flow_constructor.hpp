@@ -2,7 +2,8 @@
 // (scene_flow_constructor/include/scene_flow_constructor.h:33-275) for the part of the class that is on the hot path:
 // construct(), the previous-frame state of stereoCallback() and reconfigureCB().  Same member names, same argument
 // meaning, same "publish nothing when an input is missing" behaviour — the per-pixel work goes through the C ABI
-// (include/mod_sf.h) to the HIP kernels.  Estimators (SGM / PWC-Net / viso2), TF and ROS wiring are out of scope.
+// (include/mod_sf.h) to the HIP kernels.  estimateDisparity() is here as well (the on-GPU SGM of SURVEY.md section 8(f) row 3); the
+// other estimators (PWC-Net / viso2), TF and ROS wiring are out of scope.
 #pragma once
 #include <functional>
 #include <stdexcept>
@@ -41,6 +42,32 @@ class SceneFlowConstructor {
     ModParams p = currentParams();
     p.dynamic_flow_diff = config.dynamic_flow_diff;
     check(mod_set_params(ctx_, &p));
+  }
+
+  // estimateDisparity() (scene_flow_constructor.cpp:258-279): sgm_gpu_->computeDisparity(left, right, infos, disparity).  Fills
+  // `disparity` as that call does for its caller — the stereo_msgs/DisparityImage contract DisparityImageProcessor reads
+  // (disparity_image_processor.cpp:25-27,41-45): 32FC1 pixels with -1 = min_disparity - 1 where no match was found, f from the
+  // left projection matrix, T = the baseline -P_right[3] / P_right[0], min_disparity 0, max_disparity D - 1 — into `pixels`, which
+  // the message then points at.  Returns false (and leaves `disparity` alone) when an image is missing or of the wrong size: the
+  // reference then resets disparity_now_, i.e. the caller passes a null disparity on.
+  void setDisparityParams(const ModSgmParams &p) { sgm_ = p; }
+  bool estimateDisparity(const mod_host::Image *left_image, const mod_host::Image *right_image, const mod_host::CameraInfo &left_camera_info,
+                         const mod_host::CameraInfo &right_camera_info, mod_host::DisparityImage *disparity, std::vector<float> *pixels) {
+    if (!left_image || !right_image || !left_image->data || !right_image->data) return false;
+    if (left_image->width != left_camera_info.width || left_image->height != left_camera_info.height ||
+        right_image->width != left_image->width || right_image->height != left_image->height) return false;
+    pixels->resize((size_t)left_image->width * left_image->height);
+    const int rc = mod_sgm_compute_host(ctx_, left_image->data, right_image->data, &sgm_, pixels->data());
+    if (rc > 0) return false;
+    check(rc);
+    disparity->header = left_image->header;
+    disparity->width = left_image->width; disparity->height = left_image->height;
+    disparity->data = pixels->data();
+    disparity->f = (float)left_camera_info.P[0];
+    disparity->T = (float)(-right_camera_info.P[3] / right_camera_info.P[0]);
+    disparity->min_disparity = 0.0f;
+    disparity->max_disparity = (float)(sgm_.disparities - 1);
+    return true;
   }
 
   // construct() (scene_flow_constructor.cpp:91-147).  Null pointers play the role of the reference's empty shared_ptrs.
@@ -203,6 +230,7 @@ class SceneFlowConstructor {
   void check(int rc) { if (rc < 0) throw std::runtime_error(std::string("libmod_sf: ") + mod_last_error(ctx_)); }
 
   ModContext *ctx_;
+  ModSgmParams sgm_{128, 6, 96, 8, 1, 1};   // the published configuration of the estimator (oracle/sgm_ref.cpp)
   int image_width_ = 0, image_height_ = 0;
   int max_objects_ = 1024;
   bool have_previous_ = false;

@@ -13,9 +13,9 @@
 #include "../../moving_object_detector_amd/host/scene_flow_constructor.hpp"
 
 template <class T>
-static std::vector<T> read_all(const std::string &p) {
+static std::vector<T> read_all(const std::string &p, bool optional = false) {
   FILE *f = fopen(p.c_str(), "rb");
-  if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
+  if (!f) { if (optional) return {}; fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
   fseek(f, 0, SEEK_END);
   long n = ftell(f);
   fseek(f, 0, SEEK_SET);
@@ -143,6 +143,37 @@ int main(int argc, char **argv) {
   }
   write_all(dir + "/objects.f64", o.data(), o.size() * 8);
   mod_destroy(ctx);
+
+  // estimateDisparity() (scene_flow_constructor.cpp:258-279) on a rectified mono8 pair, when the directory holds one
+  auto sgm_dims = read_all<double>(dir + "/sgm_dims.f64", /*optional=*/true);
+  if (sgm_dims.size() == 2) {
+    const int SW = (int)sgm_dims[0], SH = (int)sgm_dims[1];
+    auto limg = read_all<uint8_t>(dir + "/sgm_left.u8"), rimg = read_all<uint8_t>(dir + "/sgm_right.u8");
+    ModConfig scfg{};
+    scfg.device = 0; scfg.max_width = SW; scfg.max_height = SH; scfg.max_frames = 1; scfg.max_objects = 64;
+    ModContext *sctx = nullptr;
+    if (mod_create(&scfg, &sctx) != MOD_OK) { fprintf(stderr, "mod_create (sgm) failed\n"); return 20; }
+    scene_flow_constructor::SceneFlowConstructor est(sctx);
+    mod_host::CameraInfo li, ri;
+    li.width = ri.width = SW; li.height = ri.height = SH;
+    li.P[0] = ri.P[0] = 700.0; li.P[5] = ri.P[5] = 700.0; li.P[2] = ri.P[2] = SW / 2.0; li.P[6] = ri.P[6] = SH / 2.0;
+    ri.P[3] = -700.0 * 0.12;                        // right camera: Tx = -fx * baseline
+    mod_host::DisparityImage first;
+    first.width = SW; first.height = SH; first.f = 700.f; first.T = 0.12f; first.min_disparity = 0.f; first.max_disparity = 127.f;
+    est.setCameraInfo(li, first);
+    est.reconfigureCB({5, 1.0});                     // (a context wants camera and parameters before any work)
+    mod_host::Image left, right;
+    left.width = right.width = SW; left.height = right.height = SH; left.data = limg.data(); right.data = rimg.data();
+    left.header.stamp = mod_host::Time(7, 5u); left.header.frame_id = "left_camera";
+    mod_host::DisparityImage disp;
+    std::vector<float> pixels;
+    if (!est.estimateDisparity(&left, &right, li, ri, &disp, &pixels)) { fprintf(stderr, "estimateDisparity failed\n"); return 21; }
+    if (disp.f != 700.f || disp.T != 0.12f || disp.min_disparity != 0.f || disp.max_disparity != 127.f || disp.data != pixels.data() ||
+        disp.header.frame_id != "left_camera") { fprintf(stderr, "disparity message fields wrong\n"); return 22; }
+    if (est.estimateDisparity(nullptr, &right, li, ri, &disp, &pixels)) { fprintf(stderr, "a missing image must fail\n"); return 23; }
+    write_all(dir + "/sgm_disparity.f32", pixels.data(), pixels.size() * 4);
+    mod_destroy(sctx);
+  }
   printf("ok %zu objects\n", objs_cluster.moving_object_array.size());
   return 0;
 }

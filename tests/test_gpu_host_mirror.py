@@ -25,8 +25,14 @@ def test_host_mirror_matches_golden(path, tmp_path):
     for k in ("d_now", "d_prev", "flow"):
         np.ascontiguousarray(g[k], np.float32).tofile(f"{d}/{k}.f32")
     np.concatenate([g["t"], g["q"], [float(np.asarray(g["dt"]).item())]]).astype(np.float64).tofile(d + "/tq.f64")
+    # estimateDisparity() on the committed 320 x 240 image pair (tests/golden/sgm_320x240.npz)
+    sg = np.load(os.path.join(ROOT, "tests", "golden", "sgm_320x240.npz"))
+    np.asarray(sg["left"].shape[::-1], np.float64).tofile(d + "/sgm_dims.f64")
+    np.ascontiguousarray(sg["left"], np.uint8).tofile(d + "/sgm_left.u8")
+    np.ascontiguousarray(sg["right"], np.uint8).tofile(d + "/sgm_right.u8")
     r = subprocess.run([EXE, d], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(d + "/sgm_disparity.f32", np.float32).reshape(sg["disparity"].shape), sg["disparity"])
     H, W = g["d_now"].shape
     cloud = np.fromfile(d + "/cloud.bin", np.float32).reshape(H, W, 8)
     # dt reaches the library the way ros::Duration::toSec() forms it from (sec, nsec) stamps: exact for the fixtures' dt = 0.1
