@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64) void k_sgm_path_line(int W, int H, int D, int P
                                                       const uint32_t *__restrict__ cr, SgmOut out) {
   const int lane = threadIdx.x, line = blockIdx.x, f = blockIdx.y;
   int x, y;
-  if (line < W) { x = line; y = RY > 0 ? 0 : H - 1; }
+  if (line < W) { x = RX < 0 ? W - 1 - line : line; y = RY > 0 ? 0 : H - 1; }   // long lines first (they enter at the far end when RX < 0)
   else { x = RX > 0 ? 0 : W - 1; y = RY > 0 ? line - W + 1 : H - 2 - (line - W); }   // the entry row's own pixel is a row line
   const size_t plane = (size_t)f * H * W, vol = plane * D;
   cl += plane; cr += plane;
