@@ -1,3 +1,6 @@
+# SQ instruction counters of k_ccl_tile per cumulative phase: the ablation build returns from the kernel after a phase (MOD_DEBUG bits
+# 1<<14 .. 1<<18, 256 = without phase B).  Needs (here, before gpurun): make -C moving_object_detector_amd/csrc ABLATE=1 CHECKED=1 OUT=../libmod_sf_ablate.so
+# usage (GPU box, repo root): bash tools/pmc_tile_phases.sh
 export MOD_SF_LIB=$PWD/moving_object_detector_amd/libmod_sf_ablate.so
 for d in 16384 32768 65536 131072 256 262144 0; do
   echo "== MOD_DEBUG=$d"
