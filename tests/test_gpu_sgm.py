@@ -131,6 +131,22 @@ def test_complete_estimator_matches_the_oracle(W, H, D, F, seed):
     ctx.close()
 
 
+def test_scratch_regrows_between_calls():
+    """One context, calls with growing then shrinking disparity ranges and frame counts: the estimator's scratch (two sets of census
+    planes and cost volumes, sized on first use) is re-allocated when a call needs more and reused otherwise."""
+    from oracle import pysgm
+    from oracle import sgm_numpy as sn
+    W, H = 80, 36
+    ctx = _ctx(W, H, 20)
+    for D, F, seed in ((16, 2, 1), (64, 9, 2), (128, 3, 3), (32, 20, 4), (128, 17, 5)):
+        pairs = [sn.make_stereo(W, H, seed * 100 + f, D, n_boxes=2) for f in range(F)]
+        left, right = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
+        got = _compute(ctx, left, right, D=D)
+        for f in (0, F // 2, F - 1):
+            assert np.array_equal(got[f], pysgm.compute(left[f], right[f], D, 6, 96, 8, True, True)), (D, F, f)
+    ctx.close()
+
+
 def test_config5_images_to_moving_objects(oracle):
     """BASELINE config 5's data path at its stated size: 1920 x 1080 stereo images -> on-GPU SGM disparity (now and previous) ->
     scene flow + clustering, every stage against its CPU restatement.  The disparity planes never leave the GPU."""
