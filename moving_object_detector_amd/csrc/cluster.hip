@@ -258,20 +258,41 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   lds_barrier();
   if (MOD_ABLATE(c, 1 << 15)) return;
   // ---- phase A2: vertical pre-link (the pixel straight above), one union per distinct (run, run-above) pair -----------
+  // The unions of all the wave's rows are first collected in a queue in LDS and then run ONE PER LANE: run in place they keep
+  // about eight of a row's 64 lanes busy (the first lane of each run pair) — and a wave64 instruction costs its four cycles
+  // however few lanes are active, which is what bounds this kernel.
+  constexpr int kJobCap = 128;
+  __shared__ int s_ja[NW][kJobCap], s_jb[NW][kJobCap];
+  int njobs = 0;                                     // wave-uniform
+  auto push_jobs = [&](bool rep, int ja, int jb) {
+    const uint64_t m = __ballot(rep);
+    if (m == 0) return;                              // wave-uniform
+    const int cnt = __popcll((unsigned long long)m);
+    if (njobs + cnt > kJobCap) { if (rep) lds_unite(Lt, ja, jb); return; }   // queue full (wave-uniform): unite in place
+    if (rep) {
+      const int slot = njobs + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      s_ja[w][slot] = ja; s_jb[w][slot] = jb;
+    }
+    njobs += cnt;
+  };
   auto link_up = [&](int gr) -> bool {              // grid row gr with grid row gr - 1 (tile rows and halo rows alike)
     const int me = gr * PW + NMAX + lane;
     const uint64_t both = m0[gr] & m0[gr - 1], hboth = (mL[gr] & mL[gr - 1]) >> (64 - NMAX);
     bool link = false;
     if (both != 0 && !MOD_ABLATE(c, 2048)) {                                // wave-uniform
       link = ((both >> lane) & 1ull) && !(fabsf(zt[me] - zt[me - PW]) > th);
-      int cur = ld_relaxed(&Lt[me]), last = -1;
-      wave_unite_lds(Lt, link, cur, last, ld_relaxed(&Lt[me - PW]), lane);
+      // lanes of one run looking at one run above all hold the same (label, label above) pair: the first lane of each contiguous
+      // group of equal pairs represents it.  (Labels are not refreshed afterwards: phase A3 flattens every cell.)
+      const int cur = ld_relaxed(&Lt[me]), oth = ld_relaxed(&Lt[me - PW]);
+      const int pc = wave_prev_i32(cur), po = wave_prev_i32(oth), pn = wave_prev_i32((int)link);
+      push_jobs(link && !(lane > 0 && pn && pc == cur && po == oth), cur, oth);
     }
     if (hboth != 0) {                                                       // wave-uniform: the left-halo cells, column by column
       const int hc = gr * PW + NMAX - 1 - min(lane, NMAX - 1);
       const bool hlink = lane < n && ((hboth >> (NMAX - 1 - lane)) & 1ull) && !(fabsf(zt[hc] - zt[hc - PW]) > th);
-      int cur = ld_relaxed(&Lt[hc]), last = -1;
-      wave_unite_lds(Lt, hlink, cur, last, ld_relaxed(&Lt[hc - PW]), lane);
+      const int cur = ld_relaxed(&Lt[hc]), oth = ld_relaxed(&Lt[hc - PW]);
+      const int pc = wave_prev_i32(cur), po = wave_prev_i32(oth), pn = wave_prev_i32((int)hlink);
+      push_jobs(hlink && !(lane > 0 && pn && pc == cur && po == oth), cur, oth);
     }
     return link;
   };
@@ -282,6 +303,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     upr[j] = upr[j] || link;
   }
   for (int hr = NMAX - 1 - w; hr > NMAX - n; hr -= NW) link_up(hr);
+  auto run_jobs = [&]() {
+    for (int j0 = 0; j0 < njobs; j0 += 64) {         // wave-uniform; the wave's own queue: its LDS writes are in order, no barrier
+      const int j = j0 + lane;
+      if (j < njobs) lds_unite(Lt, s_ja[w][j], s_jb[w][j]);
+    }
+    njobs = 0;
+  };
+  run_jobs();
   lds_barrier();
   if (MOD_ABLATE(c, 1 << 16)) return;
   // ---- phase A3: flatten, so that phase B can compare labels directly -------------------------------------------------
@@ -384,21 +413,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       // a tile pixel); phases A1-A3 have linked them like tile pixels, so they mostly carry this pixel's label already
       const bool need_any = (vmask & dmask) != 0;
       up = up || (vmask != 0);
-      // pass 2, rare after A1-A3: unions, one window position at a time
+      // pass 2, rare after A1-A3: the unions go to the wave's job queue (run one per lane after the last row, like phase A2's);
+      // `cur` is not refreshed meanwhile, so a pair may be queued again from a later window row — a void union, two finds
       if (!MOD_ABLATE(c, 1) && __ballot(need_any)) {
         COUNT(10, 1)
 #pragma unroll
         for (int k = 0; k <= NMAX; k++) {
           if (k > n || (dv == 0 && k == 0)) continue;
-          const int lab = ld_relaxed(&Lt[base - k]);
+          const int lab = lq[k];
           const bool need = ((vmask >> k) & 1u) && lab != cur && lab != last;
-          if (__ballot(need)) { COUNT(12, 1) wave_unite_lds(Lt, need, cur, last, lab, lane); }
+          if (__ballot(need)) {                        // wave-uniform
+            COUNT(12, 1)
+            const int pl = wave_prev_i32(lab), pc = wave_prev_i32(cur), pn = wave_prev_i32((int)need);
+            push_jobs(need && !(lane > 0 && pn && pc == cur && pl == lab), cur, lab);
+            if (need) last = lab;
+          }
         }
       }
     }
     STAMP(3)
     upr[j] = up;
   }
+  run_jobs();
   lds_barrier();
   STAMP(4)
   // ---- phase C: publish ----------------------------------------------------------------------------------------------
