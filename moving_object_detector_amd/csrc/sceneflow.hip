@@ -192,6 +192,18 @@ template <class T> __device__ __forceinline__ T ld(const void *base, uint32_t by
 template <class T> __device__ __forceinline__ void st(void *base, uint32_t byte_off, const T &v) {
   *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+// Kernel arguments that are needed late are read from the kernarg segment after the register-heavy first stage (one scalar load
+// each, issued together with the gathers so that their latency hides behind those) instead of being held in SGPRs across the
+// arithmetic: with them the kernel wants more than the 102 SGPRs a wave has and spills into VGPR lanes (v_writelane / v_readlane
+// pairs, which take VALU issue slots of a VALU-co-limited kernel).  Read through the kernarg segment pointer: taking the address of
+// a by-value parameter would make the compiler copy it to scratch.
+#define SF_K4 __attribute__((address_space(4)))
+template <class T> __device__ __forceinline__ T karg(size_t off) {
+  const SF_K4 char *kp = (const SF_K4 char *)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(const volatile SF_K4 T *)(kp + off);
+}
+constexpr size_t kSfArgsAt = (sizeof(DevCam) + alignof(SfArgs) - 1) / alignof(SfArgs) * alignof(SfArgs);   // k(DevCam c, SfArgs a)
+#define LATE_A(field) karg<decltype(SfArgs::field)>(kSfArgsAt + offsetof(SfArgs, field))
 // Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
 __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const int lane = threadIdx.x;                      // 0..63
@@ -218,6 +230,8 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const uint32_t o4 = pix * 4u, o8 = pix * 8u;
   const FrameConst fc = a.fc[f];
   uint32_t nib = 0;
+  uint64_t *out_mask = nullptr;
+  int32_t *out_hdr = nullptr;
   if (inb) {
     const float *dprev_f = a.dprev + fN;
     const float4 dn = ld<float4>(a.dnow + fN, o4);
@@ -237,7 +251,12 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
     st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
     st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
-    // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets
+    // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets; so do the scalar
+    // loads of the output pointers that are needed from here on
+    float *const out_vx = LATE_A(vx), *const out_vy = LATE_A(vy), *const out_vz = LATE_A(vz);
+    float4 *const out_aos = LATE_A(aos);
+    float *const out_depth = LATE_A(depth), *const out_sflow = LATE_A(sflow);
+    out_mask = LATE_A(mask); out_hdr = LATE_A(tilehdr);
     const uint32_t W = (uint32_t)c.W;
     const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
     const float g1 = ld<float>(dprev_f, ((uint32_t)s1.py * W + (uint32_t)s1.px) * 4u);
@@ -258,30 +277,31 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
       sf_stage2b(c, fc, s2, w2, p2);
       sf_stage2b(c, fc, s3, w3, p3);
     }
-    st(a.vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
-    st(a.vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
-    st(a.vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
-    if (a.aos) {   // pcl::PointXYZVelocity records, 32 B each (pads written as 0)
-      float4 *q = a.aos + 2 * fN;
+    st(out_vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
+    st(out_vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
+    st(out_vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
+    if (out_aos) {   // pcl::PointXYZVelocity records, 32 B each (pads written as 0)
+      float4 *q = out_aos + 2 * fN;
       const uint32_t o32 = pix * 32u;
       st(q, o32, make_float4(p0.x, p0.y, p0.z, 0.f)); st(q, o32 + 16u, make_float4(p0.vx, p0.vy, p0.vz, 0.f));
       st(q, o32 + 32u, make_float4(p1.x, p1.y, p1.z, 0.f)); st(q, o32 + 48u, make_float4(p1.vx, p1.vy, p1.vz, 0.f));
       st(q, o32 + 64u, make_float4(p2.x, p2.y, p2.z, 0.f)); st(q, o32 + 80u, make_float4(p2.vx, p2.vy, p2.vz, 0.f));
       st(q, o32 + 96u, make_float4(p3.x, p3.y, p3.z, 0.f)); st(q, o32 + 112u, make_float4(p3.vx, p3.vy, p3.vz, 0.f));
     }
-    if (a.depth) st(a.depth + fN, o4, make_float4(p0.depth, p1.depth, p2.depth, p3.depth));
-    if (a.sflow) {
-      st(a.sflow + 2 * fN, o8, make_float4(p0.s0, p0.s1, p1.s0, p1.s1));
-      st(a.sflow + 2 * fN, o8 + 16u, make_float4(p2.s0, p2.s1, p3.s0, p3.s1));
+    if (out_depth) st(out_depth + fN, o4, make_float4(p0.depth, p1.depth, p2.depth, p3.depth));
+    if (out_sflow) {
+      st(out_sflow + 2 * fN, o8, make_float4(p0.s0, p0.s1, p1.s0, p1.s1));
+      st(out_sflow + 2 * fN, o8 + 16u, make_float4(p2.s0, p2.s1, p3.s0, p3.s1));
     }
     nib = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u) | (p2.dyn ? 4u : 0u) | (p3.dyn ? 8u : 0u);
   }
-  if (a.mask) {   // wave-uniform branch; all 64 lanes take part in the shuffles
+  if (!inb) { out_mask = LATE_A(mask); out_hdr = LATE_A(tilehdr); }
+  if (out_mask) {   // wave-uniform branch; all 64 lanes take part in the shuffles
     const uint64_t w = nibbles_to_word(nib, lane);
     const int word = (bx * 64 + lane) / 16;                  // (x0 / 64)
     if ((lane & 15) == 0 && y < c.H && word < c.mask_words) {
-      a.mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
-      if (a.tilehdr && w) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + word) * 2] = 1;   // benign race: every writer stores 1
+      out_mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
+      if (out_hdr && w) out_hdr[((size_t)f * LATE_A(tiles_per_frame) + (size_t)(y / LATE_A(tile_rows)) * LATE_A(tiles_x) + word) * 2] = 1;   // benign race: every writer stores 1
     }
   }
 }
