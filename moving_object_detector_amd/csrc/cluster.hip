@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   __shared__ uint64_t m0[PH], mL[PH];
   __shared__ int s_uni[PH];                         // the one label every dynamic cell of the grid row carries after phase A3, or -1
   constexpr int kSlots = 32;
-  __shared__ int s_nreq, s_nslots;
+  __shared__ int s_nreq, s_nslots, s_anyhalo;
   __shared__ RootRec srec[kSlots];
   __shared__ int sroot[kSlots];
   // threadIdx.y is the wave index: the same in all 64 lanes, but it arrives in a vector register — as a scalar, every row
@@ -166,12 +166,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
   // ---- all HBM reads of the kernel, in ONE round trip: the mask words of the PH grid rows and the depth rows (unconditional,
   // clamped addresses; values of non-dynamic pixels are discarded: predicated loads would compile to one exec-masked branch +
   // wait each) ----
-  if (tid < PH) {
-    const int gy = y0 - NMAX + tid;
-    const bool inrow = gy >= 0 && gy < c.H && tid >= NMAX - n;
-    const uint64_t *mr = a.mask + ((size_t)f * c.H + (inrow ? gy : 0)) * MW;
-    m0[tid] = inrow ? mr[wi] : 0ull;
-    mL[tid] = (inrow && wi > 0) ? mr[wi - 1] : 0ull;
+  {
+    uint64_t q0 = 0ull, qL = 0ull;
+    if (tid < PH) {
+      const int gy = y0 - NMAX + tid;
+      const bool inrow = gy >= 0 && gy < c.H && tid >= NMAX - n;
+      const uint64_t *mr = a.mask + ((size_t)f * c.H + (inrow ? gy : 0)) * MW;
+      q0 = inrow ? mr[wi] : 0ull;
+      qL = (inrow && wi > 0) ? mr[wi - 1] : 0ull;
+      m0[tid] = q0; mL[tid] = qL;
+    }
+    if (w == 0) {                                    // PH <= 64: all mask words sit in wave 0.  Any dynamic halo cell at all?
+      const uint64_t hb = __ballot(tid < PH && (((tid < NMAX) ? q0 : 0ull) | (qL >> (64 - NMAX))) != 0ull);
+      if (lane == 0) s_anyhalo = hb != 0ull;
+    }
   }
   constexpr int AROWS = (PH + NW - 1) / NW;
   float zl[AROWS], zh[AROWS];
@@ -233,11 +241,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const uint64_t starts = mw & ~C;                // run starts: dynamic and not linked to the left
     // left-halo cells: lane j < n owns the cell in column x0-1-j; bit j of lk: it is linked to its right neighbour
     const int hc = gr * PW + NMAX - 1 - min(lane, NMAX - 1);
-    const bool hdyn = lane < n && ((ml >> (63 - lane)) & 1ull);
-    const bool rdyn = lane == 0 ? (bool)(mw & 1ull) : (bool)((ml >> (64 - lane)) & 1ull);
-    const bool hl = hdyn && rdyn && !(fabsf(zt[hc] - zt[hc + 1]) > th);
-    const uint32_t lk = (uint32_t)__ballot(hl);
-    const int m = __builtin_ctz(~lk);               // cells h0 .. h(m-1) hang on lane 0 through an unbroken chain of links
+    int m = 0;                                      // cells h0 .. h(m-1) hang on lane 0 through an unbroken chain of links
+    if ((ml >> 63) & mw & 1ull) {                   // wave-uniform: the chain starts with h0 - lane 0, both dynamic
+      const bool hdyn = lane < n && ((ml >> (63 - lane)) & 1ull);
+      const bool rdyn = lane == 0 ? (bool)(mw & 1ull) : (bool)((ml >> (64 - lane)) & 1ull);
+      const bool hl = hdyn && rdyn && !(fabsf(zt[hc] - zt[hc + 1]) > th);
+      const uint32_t lk = (uint32_t)__ballot(hl);
+      m = __builtin_ctz(~lk);
+    }
     // label of lane 0's run: its own cell — in a halo row the leftmost chained cell (parents must not be larger than children)
     const int id0 = halo_row ? ((gr * PW + NMAX - m) | kHaloBit) : (gr * PW + NMAX);
     if (dyn) {
@@ -479,7 +490,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
       const uint64_t mw = (gc >= NMAX) ? m0[gr] : mL[gr];
       return gx >= 0 && ((mw >> (gx & 63)) & 1ull);
     };
-    const bool any_halo = !MOD_ABLATE(c, 1024);
+    const bool any_halo = !MOD_ABLATE(c, 1024) && s_anyhalo;   // workgroup-uniform
     for (int i0 = 0; i0 < total && any_halo; i0 += NW * 64) {
       const int i = i0 + tid;
       if (i < total) {
