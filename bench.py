@@ -33,7 +33,7 @@ B_FUSED = 44                   # bytes/px: 16 in + 24 out + 4 label (mask never 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks of the job (default: WORLD_SIZE when a launcher set it, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=512, help="stereo pairs per step and per GPU")
@@ -51,14 +51,20 @@ def parse():
     ap.add_argument("--no-labels", action="store_true",
                     help="do not produce the cluster-label plane (the reference renders its cluster image only for subscribers)")
     ap.add_argument("--seed", type=int, default=4, help="scene seed of the synthetic stream")
+    ap.add_argument("--no-dist", action="store_true",
+                    help="N = 1 only: skip the process group (by default a one-rank RCCL group is brought up so that the single-GPU "
+                         "line drives the communicator, the device broadcast and the device all-reduce of the N-rank run)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the short config-5 leg (on-GPU SGM disparity, outside `value`)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + config broadcast + stream sharding only, no GPU work (exercises the N-rank launch path on a CPU box)")
     return ap.parse_args()
 
 
-def cpu_baseline(cam, prm, batch, n_sample):
-    """Times the oracle on this box's host cores on the first n_sample pairs of rank 0's batch."""
-    import numpy as np  # noqa: F401
+def cpu_baseline(cam, prm, batch, n_sample, sgm=None):
+    """Times the oracle on this box's host cores on the first n_sample pairs of rank 0's batch.  `sgm` = (left, right, D, gpu
+    disparity) of one frame of the config-5 leg: the CPU restatement of the disparity estimator (oracle/sgm_ref.cpp) is timed on
+    it (one frame, one core) and the GPU's plane compared with its result."""
+    import numpy as np
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import pyoracle
@@ -103,18 +109,102 @@ def cpu_baseline(cam, prm, batch, n_sample):
         "tidy_1core": res["tidy"],
         "all_cores": {"value": allcore, "threads": workers, "host_cores": cores, "mode": "faithful, frame-sharded"},
     }
+    if sgm is not None:
+        from oracle import pysgm
+        left, right, D, gpu_disp = sgm
+        pysgm.lib()
+        t0 = time.perf_counter()
+        want = pysgm.compute(left, right, D)
+        dt = time.perf_counter() - t0
+        out["config5_sgm"] = {"frames_per_s": 1.0 / dt, "cores": 1, "kind": "port", "sample": f"one {left.shape[1]}x{left.shape[0]} image pair, D = {D}, 8 paths",
+                              "gpu_disparity_matches_oracle": bool(np.array_equal(gpu_disp, want))}
     return out, refs
+
+
+def config5_leg(dev, local_rank):
+    """BASELINE config 5's data path, short and OUTSIDE `value`: synthetic stereo images -> on-GPU SGM disparity
+    (replaces sgm_gpu::SgmGpu::computeDisparity, scene_flow_constructor.cpp:35,267) -> scene flow + clusters, all HBM-resident.
+    8 frames of 1280x720 and 5 of 1920x1080 per step (one SGM group each).  Prices the disparity estimator against its HBM
+    roofline (8 paths x D bytes/px written + read back = 2 KB/px at D = 128) and its VALU bound.  Returns (numbers, check):
+    `check` = (left, right, D, GPU disparity) of one 720p frame, which cpu_baseline() hands to the CPU restatement."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+
+    D, PATHS = 128, 8
+    check = None
+    out = {"disparities": D, "paths": PATHS, "data": "synthetic stereo images with moving boxes; flow = 0 + a shift on the boxes; identity ego-motion"}
+    for (W, H, F, key) in ((1280, 720, 8, "720"), (1920, 1080, 5, "1080")):
+        imgs = [synth.make_stereo_images(W, H, 300 + k, D, n_boxes=5) for k in range(2)]
+        cam = synth.make_camera(W, H)
+        cam.min_disparity, cam.max_disparity = np.float32(0.0), np.float32(D - 1)
+        ctx = Context(W, H, max_frames=F, device=local_rank)
+        ctx.set_camera(cam)
+        ctx.set_params(synth.Params())
+        idx = [i % 2 for i in range(F)]
+        left = torch.from_numpy(np.stack([p[0] for p in imgs])).to(dev)[idx].contiguous()
+        right = torch.from_numpy(np.stack([p[1] for p in imgs])).to(dev)[idx].contiguous()
+        # a stream that stands still (now == previous image pair, identity ego-motion) except for the boxes, which the flow moves
+        flow = torch.from_numpy(np.stack([synth.make_box_flow(p[2], shift=24.0) for p in imgs])).to(dev)[idx].contiguous()
+        ts = np.zeros((F, 3)); qs = np.tile(np.array([[0.0, 0.0, 0.0, 1.0]]), (F, 1)); dts = np.full(F, 1.0 / 15.0)
+        d_now = torch.zeros((F, H, W), dtype=torch.float32, device=dev)
+        sp = capi.ModSgmParams(D, 6, 96, PATHS, 1, 1)
+        ws = ctx.workspace(F)
+        batch = ctx.make_batch(d_now, d_now, flow, ts, qs, dts)      # previous = now: the same image pair twice
+
+        def step():
+            rc = ctx.lib.mod_sgm_compute_dev(ctx.h, F, left.data_ptr(), right.data_ptr(), C.byref(sp), d_now.data_ptr())
+            assert rc == 0, rc
+            ev[1].record()
+            assert ctx.process(batch, ws) == 0
+
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        step()
+        torch.cuda.synchronize()
+        steps, sgm_ms = 4, 0.0
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ev[0].record()
+            step()
+            ev[2].record()
+            torch.cuda.synchronize()
+            sgm_ms += ev[0].elapsed_time(ev[1])
+        el = time.perf_counter() - t0
+        sgm_frame_ms = sgm_ms / (steps * F)
+        out["pairs_per_s_" + key] = F * steps / el
+        out["sgm_ms_per_frame_" + key] = sgm_frame_ms
+        out["objects_per_frame_" + key] = float(ws["n_objects"].float().mean())
+        out["valid_disparity_share_" + key] = float((d_now >= 0).float().mean())
+        if key == "720":
+            n = W * H
+            gbs = 2 * PATHS * D * n / (sgm_frame_ms * 1e-3) / 1e9
+            # a path step is ~30 VALU instructions per wave (DESIGN.md 3.4), 4 cycles each, over 1024 SIMDs at 2.4 GHz
+            valu_ms = PATHS * n * 30 * 4 / (1024 * 2.4e9) * 1e3
+            out["sgm_ms_per_frame"] = sgm_frame_ms
+            out["sgm_roofline"] = {"bytes_per_px": 2 * PATHS * D, "GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "valu_bound_ms": valu_ms,
+                                   "frac_of_valu_bound": valu_ms / sgm_frame_ms, "at": "1280x720, 8 frames per group"}
+            check = (imgs[0][0], imgs[0][1], D, d_now[0].cpu().numpy())
+        ctx.close()
+        del left, right, flow, d_now, ws, batch
+        torch.cuda.empty_cache()
+    return out, check
 
 
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and args.gpus > 1:
+    if env_world is None and (args.gpus or 1) > 1:
         # `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call (torch is not even imported),
         # starts N fresh ranks exactly as the driver would (torch.distributed.run, one process per GPU) and relays their exit code.
         from moving_object_detector_amd.launch import spawn_ranks
         sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     world = int(env_world or "1")
+    if args.gpus is None:
+        args.gpus = world                     # started by a launcher without --gpus: WORLD_SIZE is the job's size
     if world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU and pass the same N\n")
         sys.exit(2)
@@ -136,12 +226,18 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if not args.launch_check else torch.device("cpu")
     on_dev = args.backend == "nccl" and not args.launch_check
+    backend = "gloo" if args.launch_check else args.backend
+    group_error = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if on_dev:
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo" if args.launch_check else args.backend)
+        mdist.init_group(backend, rank, world, device=dev if on_dev else None)   # "nccl" is RCCL on ROCm
+    elif not args.no_dist and not args.launch_check:
+        # one rank: the same group code, on a communicator of one (RCCL is loaded and runs the broadcast / all-reduce kernels
+        # on this GPU).  A box whose RCCL cannot come up still gets its line: the failure is reported, not hidden.
+        try:
+            mdist.init_group(backend, 0, 1, device=dev if on_dev else None)
+        except Exception as e:                               # noqa: BLE001
+            group_error = f"{type(e).__name__}: {e}"[:300]
+    group_up = mdist.group_is_up()
 
     W, H, F = args.width, args.height, args.frames
     G = max(1, min(args.distinct, F))
@@ -159,7 +255,7 @@ def main():
         if rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": world, "backend": "gloo", "camera_width": cam_s.width,
                               "cluster_size": prm_s.cluster_size, "shards": [c.tolist() for c in counts]}))
-        if world > 1:
+        if group_up:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -191,7 +287,7 @@ def main():
     batch = ctx.make_batch(d_now, d_prev, flow, ts, qs, dts)
 
     def barrier():
-        if world > 1:
+        if group_up:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -218,10 +314,7 @@ def main():
     torch.cuda.synchronize()
     stage = [ctx.stage_time(i) for i in range(capi.MOD_STAGE_COUNT)]
     ctx.set_profiling(False)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = mdist.max_over_ranks(elapsed, device=dev if on_dev else None)     # the slowest rank's time (device all-reduce on RCCL)
 
     if rank == 0:
         N = W * H
@@ -255,7 +348,9 @@ def main():
             "frames_per_launch": F, "avg_launch_ms": ms[dom],
             "measured_in": "timed region" if dom == capi.MOD_STAGE_SCENE_FLOW else "breakdown pass (all stage timers on)",
             "scene_flow_ms_in_breakdown_pass": breakdown_sf_ms, "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
-            "traffic_source": (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 + WRITE_SIZE, same command)"
+            "traffic_from_committed_profile": traffic is not None,       # a separate rocprofv3 --pmc run of this command, not this run
+            "traffic_source": (f"profiles/{os.path.basename(tpath)} at commit {tj.get('head', '?')} (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 + "
+                               f"WRITE_SIZE in separate passes of this same command; counters cannot be read inside the run)"
                                if traffic else None),
             "kernels_ms_per_launch": kernels,
             "groups": {
@@ -264,16 +359,26 @@ def main():
                 "fused_end_to_end": {"GBps": F * N * B_FUSED / ((sf_ms + cl_ms) * 1e-3) / 1e9, "bytes_per_px": B_FUSED},
             },
         }
+        n_chk = min(args.cpu_sample, G)
+        planes = ws["planes"][:, :n_chk].cpu().numpy()   # the sampled pairs' outputs, for the same-run check against the oracle
+        labels = ws["labels"][:n_chk].cpu().numpy() if ws["labels"] is not None else None
+        c5 = c5_check = None
+        if not args.no_config5:
+            ctx.close()                                       # frees the 512-pair context's scratch before the SGM volumes come
+            ctx._ws = None
+            del batch, ws, d_now, d_prev, flow
+            torch.cuda.empty_cache()
+            try:
+                c5, c5_check = config5_leg(dev, local_rank)
+            except Exception as e:                            # noqa: BLE001  (the leg is outside `value`; its failure must not cost the line)
+                c5 = {"error": f"{type(e).__name__}: {e}"[:300]}
         cpu = None
         if not args.no_cpu_baseline:                     # rank 0 only, also when N > 1 (the other ranks wait at the last barrier)
             prm = synth.Params()
-            cpu, refs = cpu_baseline(cam, prm, host, args.cpu_sample)
-            # same-run output check of the sampled pairs against the oracle
-            planes = ws["planes"][:, :len(refs)].cpu().numpy()
-            labels = ws["labels"][:len(refs)].cpu().numpy() if ws["labels"] is not None else None
+            cpu, refs = cpu_baseline(cam, prm, host, args.cpu_sample, sgm=c5_check)
             ok = True
             for f, (ref, lab, objs) in enumerate(refs):
-                if f >= G:
+                if f >= n_chk:
                     break
                 for i, k in enumerate(PLANES):
                     a, r = planes[i, f], ref[k]
@@ -293,12 +398,18 @@ def main():
                        "stream": ("one synthetic stream, contiguous chunk per rank + one disparity plane of halo" if args.workload == "sequence"
                                   else "independent synthetic pairs per rank"),
                        "sharding": f"frames x{world}",
-                       "collective": "one RCCL broadcast of the intrinsics/params block before the timed region"},
+                       "collective": ("one broadcast of the intrinsics/params block before the timed region + one all-reduce (MAX) of the elapsed time"
+                                      if group_up else "none: no process group in this run"),
+                       "collective_executed": bool(group_up), "collective_backend": (dist.get_backend() if group_up else None),
+                       "collective_on_device": bool(group_up and on_dev), "collective_world_size": (dist.get_world_size() if group_up else 0),
+                       "collective_error": group_error},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if c5 is not None:
+            line["config5"] = c5
         print(json.dumps(line))
     ctx.close()
-    if world > 1:
+    if group_up:
         dist.barrier()
         dist.destroy_process_group()
 

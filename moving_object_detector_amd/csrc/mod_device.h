@@ -20,7 +20,7 @@
 // before it is used; a violation is counted in ClArgs.dbg[48 + code] and the access is skipped instead of faulting the GPU.
 // A product build compiles the conditions away.  Codes: 0 link request pixel, 1 link roots, 2 merge root, 3 root list slot,
 // 4 select root, 5 final: parent entry, 6 final: tile-root cell, 7 final: label, 8 final: member slot, 9 median: segment,
-// 10 median: member pixel, 11 ties: member slot, 12 (unused), 13 tile: root pixel, 14 ties: members placed != cluster size,
+// 10 median: member pixel, 11 ties: member slot, 12 scene flow: a late kernarg load disagrees with the argument it stands for, 13 tile: root pixel, 14 ties: members placed != cluster size,
 // 15 select: more clusters than max_objects.
 #ifdef MOD_CHECKED
 #define MOD_CHECK(a, cond, code) ((cond) ? true : (atomicAdd(&(a).dbg[48 + (code)], 1ull), false))

@@ -12,6 +12,7 @@ struct SfArgs {
   const FrameConst *fc;               // [F] device
   int32_t *tilehdr;                   // [F][tiles][2] or null: header word 0 of every cluster tile with a dynamic pixel is set to 1
   int32_t tile_rows, tiles_x, tiles_per_frame;   // (zeroed by the caller beforehand); tile = 64 x tile_rows pixels
+  unsigned long long *dbg;            // the context's diagnostic counters (checked build: index assertion 12), unused by a product build
 };
 
 // Scratch the clustering kernels work in; all device pointers, sized by the context.

@@ -264,6 +264,7 @@ int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPla
   a.fc = c->b.fc;
   a.tilehdr = nullptr; a.tile_rows = ccl_tile_rows(); a.tiles_x = c->dc.mask_words;
   a.tiles_per_frame = c->dc.mask_words * ((c->dc.H + ccl_tile_rows() - 1) / ccl_tile_rows());
+  a.dbg = c->b.dbg;
   if (tile_flags && mask) {      // the clustering follows: the kernel's epilogue also marks the cluster tiles that hold a dynamic pixel
     a.tilehdr = c->b.tilehdr;
     HIP_TRY(c, hipMemsetAsync(c->b.tilehdr, 0, sizeof(int32_t) * 2 * (size_t)a.tiles_per_frame * in->frames, c->stream));
@@ -597,10 +598,12 @@ static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
   }
   if (b.sgm_S && b.sgm_D >= D && b.sgm_G >= g) return MOD_OK;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // grow-only in BOTH dimensions: calls that alternate between (few disparities, large group) and (many, small) settle on the
+  // maxima after one reallocation each instead of freeing and allocating gigabytes on every call
+  const int D2 = std::max(D, b.sgm_D), g2 = std::max(g, b.sgm_G);
   void *old[] = {b.sgm_S, b.sgm_census, b.sgm_maps};
   for (void *q : old) if (q) HIP_TRY(c, hipFree(q));
   b.sgm_S = nullptr; b.sgm_census = nullptr; b.sgm_maps = nullptr; b.sgm_D = 0; b.sgm_G = 0;
-  const int D2 = std::max(D, b.sgm_D), g2 = std::max(g, b.sgm_G);
   HIP_TRY(c, dalloc(&b.sgm_census, 2 * 2 * N * g2));                       // two sets: see mod_sgm_compute_dev
   HIP_TRY(c, dalloc(&b.sgm_maps, 4 * N * g2));
   HIP_TRY(c, dalloc(&b.sgm_S, 2 * N * (size_t)D2 * g2 * kSgmPaths));
@@ -627,30 +630,33 @@ int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, cons
   const int ngroups = (frames + group - 1) / group;
   const size_t set_census = 2 * N * group, set_volumes = N * (size_t)D * group * kSgmPaths;
   uint8_t *dl = b.sgm_maps, *dr = dl + N * group, *dlm = dr + N * group, *drm = dlm + N * group;
-  auto start = [&](int k) {
+  auto start = [&](int k) -> int {
     const int f0 = k * group, g = std::min(group, frames - f0), s = k & 1;
     uint32_t *cl = b.sgm_census + s * set_census, *cr = cl + N * g;
     launch_sgm_census(W, H, g, left + (size_t)f0 * N, cl, c->stream);
     launch_sgm_census(W, H, g, right + (size_t)f0 * N, cr, c->stream);
-    (void)hipEventRecord(b.sgm_fork[s], c->stream);
+    HIP_TRY(c, hipEventRecord(b.sgm_fork[s], c->stream));
     const size_t path_stride = N * (size_t)D * g;        // one volume [g][H][W][D] per path
     for (int i = 0; i < p->paths; i++) {
-      (void)hipStreamWaitEvent(b.sgm_side[i], b.sgm_fork[s], 0);
+      HIP_TRY(c, hipStreamWaitEvent(b.sgm_side[i], b.sgm_fork[s], 0));   // a failed wait would let a path read census planes in flight
       launch_sgm_path(W, H, g, D, p->p1, p->p2, p->paths == 4 ? order4[i] : i, cl, cr, b.sgm_S + s * set_volumes + (size_t)i * path_stride,
                       nullptr, b.sgm_side[i]);
-      (void)hipEventRecord(b.sgm_join[s][i], b.sgm_side[i]);
+      HIP_TRY(c, hipEventRecord(b.sgm_join[s][i], b.sgm_side[i]));
     }
+    return MOD_OK;
   };
-  auto finish = [&](int k) {
+  auto finish = [&](int k) -> int {
     const int f0 = k * group, g = std::min(group, frames - f0), s = k & 1;
-    for (int i = 0; i < p->paths; i++) (void)hipStreamWaitEvent(c->stream, b.sgm_join[s][i], 0);
+    // a failed wait would let the winner-take-all read volumes the path kernels are still writing: surface it
+    for (int i = 0; i < p->paths; i++) HIP_TRY(c, hipStreamWaitEvent(c->stream, b.sgm_join[s][i], 0));
     launch_sgm_finish(W, H, g, D, p->paths, N * (size_t)D * g, p->median, p->lr_check, b.sgm_S + s * set_volumes, dl, dr, dlm, drm,
                       disparity + (size_t)f0 * N, c->stream);
+    return MOD_OK;
   };
-  start(0);
+  if ((rc = start(0))) return rc;
   for (int k = 0; k < ngroups; k++) {
-    if (k + 1 < ngroups) start(k + 1);
-    finish(k);
+    if (k + 1 < ngroups && (rc = start(k + 1))) return rc;
+    if ((rc = finish(k))) return rc;
   }
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;

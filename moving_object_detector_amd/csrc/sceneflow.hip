@@ -14,6 +14,9 @@
 // of disp_prev (served by L2 — the warp target is a few rows away) and two F64 ray-table entries.
 // Arithmetic follows the reference expression by expression (F32 vs F64 as annotated); FP contraction is off so
 // that every product and sum rounds exactly like the SSE2 build of the reference.
+#include <cstddef>
+#include <type_traits>
+
 #include "exact_div.h"
 #include "mod_launch.h"
 
@@ -204,6 +207,14 @@ template <class T> __device__ __forceinline__ T karg(size_t off) {
 }
 constexpr size_t kSfArgsAt = (sizeof(DevCam) + alignof(SfArgs) - 1) / alignof(SfArgs) * alignof(SfArgs);   // k(DevCam c, SfArgs a)
 #define LATE_A(field) karg<decltype(SfArgs::field)>(kSfArgsAt + offsetof(SfArgs, field))
+// karg()/LATE_A are tied to the signature `k_scene_flow_v4(DevCam c, SfArgs a)`: by-value aggregates are laid out in the kernarg
+// segment in declaration order at their natural alignment (code object v5: explicit arguments first, hidden ones after), i.e.
+// exactly like the members of the struct below.  A change of the signature or of either struct must change this too — a wrong
+// offset would store through garbage pointers.  The checked build also compares LATE_A(vx) with a.vx at run time (code 12).
+struct SfKernargLayout { DevCam c; SfArgs a; };
+static_assert(std::is_trivially_copyable<DevCam>::value && std::is_trivially_copyable<SfArgs>::value, "kernarg structs are copied bytewise");
+static_assert(alignof(DevCam) <= 8 && alignof(SfArgs) <= 8, "kernarg segment is 8-byte aligned per argument here");
+static_assert(kSfArgsAt == offsetof(SfKernargLayout, a), "SfArgs does not sit where karg() reads it");
 // Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
 __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const int lane = threadIdx.x;                      // 0..63
@@ -254,6 +265,12 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets; so do the scalar
     // loads of the output pointers that are needed from here on
     float *const out_vx = LATE_A(vx), *const out_vy = LATE_A(vy), *const out_vz = LATE_A(vz);
+#ifdef MOD_CHECKED
+    if (out_vx != a.vx || LATE_A(tilehdr) != a.tilehdr || LATE_A(tiles_x) != a.tiles_x) {   // the late loads read what the signature passes
+      if (a.dbg) atomicAdd(&a.dbg[48 + 12], 1ull);
+      return;
+    }
+#endif
     float4 *const out_aos = LATE_A(aos);
     float *const out_depth = LATE_A(depth), *const out_sflow = LATE_A(sflow);
     out_mask = LATE_A(mask); out_hdr = LATE_A(tilehdr);

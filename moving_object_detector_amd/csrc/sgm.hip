@@ -1,11 +1,12 @@
-// sgm.hip — on-GPU disparity estimation, first stages (BASELINE config 5).
+// sgm.hip — on-GPU disparity estimation, the complete estimator (BASELINE config 5).
 //
-// Replaces (when finished) sgm_gpu::SgmGpu::computeDisparity, the un-vendored CUDA estimator the reference calls at
+// Replaces sgm_gpu::SgmGpu::computeDisparity, the un-vendored CUDA estimator the reference calls at
 // scene_flow_constructor/src/scene_flow_constructor.cpp:35,267; its output contract is the stereo_msgs/DisparityImage consumed at
 // disparity_image_proc/src/disparity_image_processor.cpp:25-27,41-42.  The algorithm (centre-symmetric 9 x 7 census, Hamming
 // cost over D <= 128 disparities, 8-path semi-global aggregation with P1 / P2, winner-take-all, median, left-right check) and
 // every choice the publication leaves open are stated in oracle/sgm_ref.cpp, which these kernels match bit for bit.
-// This round: the census transform and the two HORIZONTAL aggregation paths (cost computed on the fly, never stored unless asked).
+// Kernels: census transform, the eight aggregation paths (matching cost computed on the fly, never stored unless asked),
+// winner-take-all over the summed paths (left and right disparity), 3 x 3 median, left-right check.
 #include "mod_launch.h"
 
 namespace {

@@ -30,9 +30,47 @@ def unpack_config(block: np.ndarray):
     return cam, prm
 
 
+def init_group(backend: str, rank: int, world: int, device=None, port: int | None = None) -> bool:
+    """Joins the job's process group — also when the job has ONE rank, so that the single-GPU run drives the very code the
+    N-rank run does (RCCL communicator, device broadcast, device all-reduce).  `backend` "nccl" is RCCL on ROCm and wants
+    `device` (its `device_id`); "gloo" is for CPU tests / rehearsals.  MASTER_ADDR / MASTER_PORT come from the launcher; a
+    lone rank without one rendezvouses with itself on 127.0.0.1.  Returns True when a group is up."""
+    if not dist.is_available():
+        return False
+    if dist.is_initialized():
+        return True
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        if world != 1 and port is None:
+            raise RuntimeError("MASTER_PORT is not set: start the ranks with a launcher (torch.distributed.run, launch.spawn_ranks)")
+        from .launch import free_port
+        os.environ["MASTER_PORT"] = str(port or free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return True
+
+
+def group_is_up() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """The job's time is the slowest rank's: all-reduce (MAX) of one F64, on `device` when the backend is RCCL."""
+    if not group_is_up():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def broadcast_config(cam, prm, src: int = 0, device=None):
-    """Rank `src` supplies (cam, prm); every rank returns the same structs.  Other ranks may pass None."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """Rank `src` supplies (cam, prm); every rank returns the same structs.  Other ranks may pass None.  Runs whenever a
+    process group is up — a one-rank group included, where the broadcast still goes through the backend's communicator."""
+    if not group_is_up():
         return cam, prm
     t = torch.zeros(_BLOCK_BYTES, dtype=torch.uint8, device=device if device is not None else "cpu")
     if dist.get_rank() == src:
@@ -78,7 +116,7 @@ def local_stream(make, total_frames: int, rank: int, world: int):
 
 def gather_counts(local_counts: torch.Tensor):
     """Optional ordered view for rank 0: all-gather of per-frame object counts (equal shard sizes)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not group_is_up():
         return [local_counts]
     out = [torch.empty_like(local_counts) for _ in range(dist.get_world_size())]
     dist.all_gather(out, local_counts)

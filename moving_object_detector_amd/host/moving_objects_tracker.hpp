@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "messages.hpp"
@@ -141,8 +142,10 @@ class MovingObjectsTracker {
     const mod_host::Time stamp = moving_objects.header.stamp;
     for (auto &t : trackers_) t->predict(stamp);              // predict (:136-140)
     correct(stamp, transformed);
-    if (tracked) {
-      tracked->header = moving_objects.header;
+    if (tracked) {                                             // header: odom frame, stamp of the input (:83-84); seq is left at 0
+      tracked->header = mod_host::Header();
+      tracked->header.frame_id = odom_frame_id_;
+      tracked->header.stamp = stamp;
       tracked->moving_object_array.clear();
     }
     if (covariances) covariances->clear();
@@ -164,6 +167,7 @@ class MovingObjectsTracker {
     }
   }
   size_t trackerCount() const { return trackers_.size(); }
+  void setOdomFrame(const std::string &frame) { odom_frame_id_ = frame; }   // param "odom_frame", default "odom" (:44)
 
  private:
   struct Association { int tracker, observation; double distance; };
@@ -227,6 +231,7 @@ class MovingObjectsTracker {
   }
 
   MovingObjectsTrackerConfig cfg_;
+  std::string odom_frame_id_ = "odom";
   std::vector<std::shared_ptr<KalmanTracker>> trackers_;
   long id_gen_ = 0;
 };

@@ -56,6 +56,9 @@ class SceneFlowConstructor {
     if (!left_image || !right_image || !left_image->data || !right_image->data) return false;
     if (left_image->width != left_camera_info.width || left_image->height != left_camera_info.height ||
         right_image->width != left_image->width || right_image->height != left_image->height) return false;
+    // the library copies the CONTEXT's width x height bytes from each image: an image of another size than the configured camera
+    // would be over-read (setCameraInfo() ran on the first frame, scene_flow_constructor.cpp:368-375)
+    if (image_width_ > 0 && (left_image->width != image_width_ || left_image->height != image_height_)) return false;
     pixels->resize((size_t)left_image->width * left_image->height);
     const int rc = mod_sgm_compute_host(ctx_, left_image->data, right_image->data, &sgm_, pixels->data());
     if (rc > 0) return false;
@@ -81,7 +84,9 @@ class SceneFlowConstructor {
       depth_image->clear();
       if (disparity_now) {
         depth_image->resize((size_t)image_width_ * image_height_);
-        check(mod_depth_image_host(ctx_, disparity_now->data, depth_image->data()));
+        const int drc = mod_depth_image_host(ctx_, disparity_now->data, depth_image->data());
+        check(drc);
+        if (drc > 0) depth_image->clear();   // a message without pixels: the reference publishes no depth image either
       }
     }
     ModTransform tf{};

@@ -454,3 +454,14 @@ def make_stereo_images(W: int, H: int, seed: int = 0, D: int = 128, n_boxes: int
     left = np.clip(left.astype(np.int32) + noise[0], 0, 255).astype(np.uint8)
     right = np.clip(right.astype(np.int32) + noise[1], 0, 255).astype(np.uint8)
     return left, right, truth
+
+
+def make_box_flow(truth: np.ndarray, shift: float = 24.0) -> np.ndarray:
+    """Optical flow (H, W, 2) for a stereo pair of make_stereo_images seen twice by a camera that stands still: zero on the
+    background, (-shift, 0) on the boxes (every layer nearer than the background), i.e. a box pixel was `shift` pixels to the
+    right in the previous frame.  With identity ego-motion the residual against the static flow is `shift` px on the boxes
+    (dynamic at the reference's default dynamic_flow_diff = 5) and 0 elsewhere, so the clusterer finds the boxes."""
+    H, W = truth.shape
+    flow = np.zeros((H, W, 2), np.float32)
+    flow[truth > truth.min(), 0] = -np.float32(shift)
+    return flow

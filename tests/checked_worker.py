@@ -69,36 +69,38 @@ def main():
     # 4. odd sizes: partial tiles at the right and bottom edges, width not a multiple of 4
     cam, bo = synth.make_batch(333, 187, 2, seed=5)
     run("odd size", cam, synth.Params(dynamic_flow_diff=1, cluster_size=5, depth_diff=0.01), bo, [0, 1])
-    # 5. one tied cluster whose bounding box needs several runs of the tie replay's cell table, clusterer alone, no labels plane
+    # 5. one tied cluster whose bounding box needs several runs of the tie replay's cell table, clusterer alone, NO labels plane:
+    #    (8256, 8) is the shape and the pass that aborted on 2026-10-04 10:53 (the tie replay's image-scan fallback
+    #    still read the labels plane, which this pass does not pass); (2304, 260) has several 64-row segments per column
     from moving_object_detector_amd.pipeline import PLANES as PL
-    W, H = 2304, 260
-    rng = np.random.default_rng(9)
-    dyn = rng.random((H, W)) < 0.97
-    dyn[:, :3] = False
-    base = rng.uniform(0.4, 1.5, size=(2, 3)).astype(np.float32)
-    v = base[rng.integers(0, 2, size=(H, W))] * rng.choice(np.array([-1.0, 1.0], np.float32), size=(H, W, 3))
-    v[~dyn] = 0.0
-    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
-    cloud = {"x": xs * 0.01, "y": ys * 0.01, "z": np.full((H, W), 5.0, np.float32), "vx": np.ascontiguousarray(v[..., 0]),
-             "vy": np.ascontiguousarray(v[..., 1]), "vz": np.ascontiguousarray(v[..., 2])}
-    prm = synth.Params(cluster_size=1000, neighbor_distance=4)
-    ctx = Context(W, H, max_frames=1, max_objects=W * H // 1000 + 1)
-    ctx.set_camera(synth.make_camera(W, H)); ctx.set_params(prm)
-    ws = ctx.workspace(1, labels=False)
-    for i, k in enumerate(PL):
-        ws["planes"][i, 0].copy_(torch.from_numpy(cloud[k]))
-    for _ in range(2):
-        assert ctx.cluster(1, ws, mask_ready=False) == 0
-        ctx.synchronize()
-    out = (C.c_uint64 * 64)()
-    ctx.lib.mod_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-    assert ctx.lib.mod_debug_counters(ctx.h, out) == 0
-    counters[:] += np.frombuffer(out, np.uint64)
-    lab, ro, K = pyoracle.cluster(cloud, prm, "tidy", max_objects=W * H)
-    assert K == 1 and ro[0]["ambiguous"]
-    compare_objects(ctx.objects_to_host(ws)[0], ro, strict_velocity=True)
-    ctx.close()
-    ran.append("wide tied cluster, no labels plane")
+    for W, H in ((8256, 8), (2304, 260)):
+        rng = np.random.default_rng(9)
+        dyn = rng.random((H, W)) < 0.97
+        dyn[:, :3] = False
+        base = rng.uniform(0.4, 1.5, size=(2, 3)).astype(np.float32)
+        v = base[rng.integers(0, 2, size=(H, W))] * rng.choice(np.array([-1.0, 1.0], np.float32), size=(H, W, 3))
+        v[~dyn] = 0.0
+        ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+        cloud = {"x": xs * 0.01, "y": ys * 0.01, "z": np.full((H, W), 5.0, np.float32), "vx": np.ascontiguousarray(v[..., 0]),
+                 "vy": np.ascontiguousarray(v[..., 1]), "vz": np.ascontiguousarray(v[..., 2])}
+        prm = synth.Params(cluster_size=1000, neighbor_distance=4)
+        ctx = Context(W, H, max_frames=1, max_objects=W * H // 1000 + 1)
+        ctx.set_camera(synth.make_camera(W, H)); ctx.set_params(prm)
+        ws = ctx.workspace(1, labels=False)
+        for i, k in enumerate(PL):
+            ws["planes"][i, 0].copy_(torch.from_numpy(cloud[k]))
+        for _ in range(2):
+            assert ctx.cluster(1, ws, mask_ready=False) == 0
+            ctx.synchronize()
+        out = (C.c_uint64 * 64)()
+        ctx.lib.mod_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        assert ctx.lib.mod_debug_counters(ctx.h, out) == 0
+        counters[:] += np.frombuffer(out, np.uint64)
+        lab, ro, K = pyoracle.cluster(cloud, prm, "tidy", max_objects=W * H)
+        assert K == 1 and ro[0]["ambiguous"]
+        compare_objects(ctx.objects_to_host(ws)[0], ro, strict_velocity=True)
+        ctx.close()
+        ran.append(f"wide tied cluster {W}x{H}, no labels plane")
     print(json.dumps({"ran": ran, "violations": {str(i - 48): int(v) for i, v in enumerate(counters) if i >= 48}}))
 
 

@@ -16,6 +16,7 @@ int main() {
     if (scanf("%u %u %d", &sec, &nsec, &n) != 3) return 2;
     mod_host::MovingObjectArray in, out;
     in.header.stamp = mod_host::Time(sec, nsec);
+    in.header.frame_id = "zed_left_camera_optical_frame";
     for (int i = 0; i < n; i++) {
       mod_host::MovingObject o{};
       double payload;
@@ -27,6 +28,8 @@ int main() {
     std::vector<moving_object_tracker::TrackerCovariance> cov;
     tracker.movingObjectsCallback(in, identity, &out, &cov);
     if (cov.size() != out.moving_object_array.size()) return 3;
+    // tracked array: odom frame + the input's stamp (moving_objects_tracker.cpp:83-84), not the camera frame of the detections
+    if (out.header.frame_id != "odom" || out.header.stamp.sec != sec || out.header.stamp.nsec != nsec) return 4;
     std::sort(out.moving_object_array.begin(), out.moving_object_array.end(), [](const mod_host::MovingObject &a, const mod_host::MovingObject &b) { return a.id < b.id; });
     printf("%zu", out.moving_object_array.size());
     for (const auto &o : out.moving_object_array)

@@ -1,6 +1,6 @@
 """Helper PROGRAM (not a test): one rank of a sharded stream on the real HIP path.
 
-Started by tests/test_gpu_sharded_stream.py as `python tests/shard_worker.py rank world port out_dir W H total seed`
+Started by tests/test_gpu_sharded_stream.py as `python tests/shard_worker.py rank world port out_dir W H total seed [defaults]`
 (fresh child processes; the ranks rendezvous over gloo and may share cuda:0 on a one-GPU box).  Rank 0 owns the camera and the
 parameters and broadcasts them; every rank materialises its chunk of the stream + the one-plane disparity halo
 (dist.local_stream), runs mod_process_dev over it and saves planes / labels / objects for the parent to concatenate.
@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     out_dir, W, H, total, seed = sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+    defaults = len(sys.argv) > 9 and sys.argv[9] == "defaults"       # the reference's default parameters (BASELINE config 4)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -26,11 +27,11 @@ def main():
     if world > 1:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        mdist.init_group("gloo", rank, world)       # both ranks share cuda:0 here; RCCL refuses two ranks on one device
     cam_s = prm_s = None
     if rank == 0:
         cam_s = capi.camera_struct(synth.make_camera(W, H))
-        prm_s = capi.params_struct(synth.Params(dynamic_flow_diff=2, cluster_size=120, neighbor_distance=4))
+        prm_s = capi.params_struct(synth.Params() if defaults else synth.Params(dynamic_flow_diff=2, cluster_size=120, neighbor_distance=4))
     cam_s, prm_s = mdist.broadcast_config(cam_s, prm_s, src=0)
     mk = lambda first, frames: synth.make_sequence(W, H, frames, seed=seed, first=first)[1]
     sh = mdist.local_stream(mk, total, rank, world)

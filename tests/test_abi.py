@@ -103,3 +103,22 @@ def test_product_does_not_reach_the_oracle():
         if isinstance(fn, ast.FunctionDef):
             uses = any(isinstance(n, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(n) for n in ast.walk(fn))
             assert not uses or fn.name == "cpu_baseline", fn.name
+
+
+def test_only_k_final_touches_the_optional_labels_plane():
+    """The cluster-label plane is optional (NULL = not wanted).  The GPU abort of 2026-10-04 10:53 was a kernel
+    other than k_final — the tie replay's image-scan fallback — still reading it.  Source-level pin: `a.labels` appears in
+    k_final only, and every store there sits behind a test of the pointer."""
+    import re
+    src = open(os.path.join(ROOT, "moving_object_detector_amd", "csrc", "cluster.hip")).read()
+    starts = [(m.start(), m.group(1)) for m in re.finditer(r"__global__[^\n]*\bvoid\s+(\w+)\s*\(", src)]
+    uses = [m.start() for m in re.finditer(r"\ba\.labels\b", src)]
+    assert uses, "k_final is expected to write the labels plane"
+    for u in uses:
+        owner = [name for pos, name in starts if pos < u][-1]
+        assert owner == "k_final", f"a.labels used in {owner}"
+    lines = src.splitlines()
+    for i, line in enumerate(lines):
+        if re.search(r"\ba\.labels\s*\[", line):                     # an access: guarded on this line or by the enclosing `if (a.labels)`
+            ctx = " ".join(lines[max(0, i - 2): i + 1])
+            assert re.search(r"if\s*\(\s*a\.labels\b", ctx), f"cluster.hip:{i + 1}: unguarded access to the labels plane"

@@ -21,5 +21,5 @@ def test_no_index_violation_on_the_critical_shapes():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert len(out["ran"]) == 6
+    assert len(out["ran"]) == 7
     assert all(v == 0 for v in out["violations"].values()), out["violations"]

@@ -52,3 +52,9 @@ def test_host_mirror_matches_golden(path, tmp_path):
     for o, e in zip(objs, want):
         assert int(o[0]) == e["id"] and np.array_equal(o[4:8], [0, 0, 0, 1])
         assert np.array_equal(o[1:4], e["center"]) and np.array_equal(o[11:14], e["bounding_box"])
+        # velocity = the cluster's median member (clusterer_nodelet.cpp:168-174), widened to F64 in the message
+        if not e["ambiguous"]:
+            assert np.array_equal(o[8:11], np.asarray(e["velocity"], np.float64)), (o[8:11], e["velocity"])
+        else:   # a tie between different vectors: the fixture (numpy, no std::sort) only pins the norm
+            norm = lambda v: np.float32(np.sqrt(np.float32(v[0]) ** 2 + (np.float32(v[1]) ** 2 + np.float32(v[2]) ** 2)))
+            assert norm(o[8:11]) == norm(e["velocity"])

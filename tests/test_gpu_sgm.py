@@ -1,5 +1,6 @@
-"""GPU: the first on-GPU disparity stages (census transform, the two horizontal aggregation paths with the matching cost computed
-on the fly) through the C ABI, bit for bit against the CPU restatement and the committed fixture."""
+"""GPU: the on-GPU disparity estimator (census transform, the eight aggregation paths with the matching cost computed on the fly,
+winner-take-all, median, left-right check) through the C ABI, stage by stage and end to end, bit for bit against the CPU
+restatement and the committed fixture; BASELINE config 5's data path at 1920 x 1080."""
 import ctypes as C
 import os
 
@@ -65,7 +66,7 @@ def test_fixture_and_argument_checks():
     ctx = _ctx(320, 240, 1)
     cl, cr, out = _stages(ctx, g["left"][None], g["right"][None], D, int(g["P1"]), int(g["P2"]))
     assert np.array_equal(cl[0], g["census_left"]) and np.array_equal(cr[0], g["census_right"])
-    for direction, k in ((0, "path0"), (1, "path1")):
+    for direction, k in ((i, f"path{i}") for i in range(8)):        # all eight aggregation paths are pinned
         L, Cv = out[direction]
         assert np.array_equal(Cv[0][g["rows"]], g["cost_rows"])
         assert np.array_equal(L[0][g["rows"]], g[k + "_rows"]) and np.array_equal(L[0].astype(np.uint32).sum(axis=2), g[k + "_sum"])
@@ -138,7 +139,8 @@ def test_scratch_regrows_between_calls():
     from oracle import sgm_numpy as sn
     W, H = 80, 36
     ctx = _ctx(W, H, 20)
-    for D, F, seed in ((16, 2, 1), (64, 9, 2), (128, 3, 3), (32, 20, 4), (128, 17, 5)):
+    # the tail alternates (many disparities, few frames) with (few, many): the scratch is grow-only in both dimensions
+    for D, F, seed in ((16, 2, 1), (64, 9, 2), (128, 3, 3), (32, 20, 4), (128, 17, 5), (128, 2, 6), (16, 20, 7), (128, 2, 8), (16, 20, 9)):
         pairs = [sn.make_stereo(W, H, seed * 100 + f, D, n_boxes=2) for f in range(F)]
         left, right = np.stack([p[0] for p in pairs]), np.stack([p[1] for p in pairs])
         got = _compute(ctx, left, right, D=D)
@@ -156,7 +158,7 @@ def test_config5_images_to_moving_objects(oracle):
     from oracle import sgm_numpy as sn
     from util import bits_equal
     W, H, D = 1920, 1080, 128
-    l0, r0, _ = sn.make_stereo(W, H, 41, D, n_boxes=5)
+    l0, r0, truth0 = sn.make_stereo(W, H, 41, D, n_boxes=5)
     l1, r1, _ = sn.make_stereo(W, H, 42, D, n_boxes=5)
     cam = synth.make_camera(W, H)
     cam.min_disparity, cam.max_disparity = np.float32(0.0), np.float32(D - 1)      # the DisparityImage fields of this estimator
@@ -187,4 +189,20 @@ def test_config5_images_to_moving_objects(oracle):
         assert bits_equal(ws["planes"][i, 0].cpu().numpy(), ref[k]), k
     labels, objs, K = oracle.cluster(ref, prm, "tidy")
     assert np.array_equal(ws["labels"][0].cpu().numpy(), labels) and int(ws["n_objects"][0]) == len(objs)
+    # a stream with something to find: the camera stands still on image pair 0 (previous = now, identity ego-motion) and the flow
+    # moves the boxes by 24 px, so the clusterer has moving objects at 1080p and the default parameters
+    from util import compare_objects
+    flow2 = synth.make_box_flow(truth0, shift=24.0)[None]
+    t2, q2 = np.zeros((1, 3)), np.array([[0.0, 0.0, 0.0, 1.0]])
+    b2 = ctx.make_batch(disp[0:1], disp[0:1], torch.from_numpy(flow2).to(dev), t2, q2, [1.0 / 15.0])
+    assert ctx.process(b2, ws) == 0
+    ctx.synchronize()
+    ref2 = oracle.construct(cam, prm, want[0], want[0], flow2[0], t2[0], q2[0], 1.0 / 15.0, "tidy")
+    for i, k in enumerate(PLANES):
+        assert bits_equal(ws["planes"][i, 0].cpu().numpy(), ref2[k]), k
+    labels2, objs2, K2 = oracle.cluster(ref2, prm, "tidy")
+    n_objects = int(ws["n_objects"][0])
+    assert n_objects > 0 and n_objects == len(objs2), (n_objects, len(objs2))
+    assert np.array_equal(ws["labels"][0].cpu().numpy(), labels2)
+    compare_objects(ctx.objects_to_host(ws)[0], objs2, strict_velocity=True)
     ctx.close()

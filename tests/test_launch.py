@@ -83,3 +83,37 @@ def test_shard_stream_chunks_plus_halo():
                 assert a["disparity_now"][-1].tobytes() == s["disparity"][a["hi"]].tobytes()
             seen += list(range(a["lo"], a["hi"]))
         assert seen == list(range(7))
+
+
+def test_launcher_without_gpus_flag_takes_world_size():
+    # `torchrun --nproc-per-node 2 bench.py` with no --gpus in the script's arguments: WORLD_SIZE is the job's size
+    from moving_object_detector_amd.launch import free_port
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--launch-check", "--distinct", "3"],
+                       env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["shards"] == [[0, 3], [3, 6]]
+
+
+def test_one_rank_group_runs_the_same_collectives_on_gloo():
+    # the group code of the N-rank run on a communicator of one (on the GPU box the same runs on RCCL: tests/test_gpu_rccl.py)
+    code = ("import sys\n"
+            "from moving_object_detector_amd import capi, synth, dist as mdist\n"
+            "import torch, torch.distributed as dist\n"
+            "assert mdist.broadcast_config('a', 'b') == ('a', 'b') and mdist.max_over_ranks(2.5) == 2.5   # no group: pass-through\n"
+            "assert mdist.init_group('gloo', 0, 1) and mdist.group_is_up() and dist.get_world_size() == 1\n"
+            "cam = capi.camera_struct(synth.make_camera(1280, 720)); prm = capi.params_struct(synth.Params(neighbor_distance=9))\n"
+            "c2, p2 = mdist.broadcast_config(cam, prm)\n"
+            "assert bytes(c2) == bytes(cam) and bytes(p2) == bytes(prm) and c2 is not cam\n"
+            "assert mdist.max_over_ranks(1.25) == 1.25\n"
+            "assert [t.tolist() for t in mdist.gather_counts(torch.tensor([3, 4], dtype=torch.int32))] == [[3, 4]]\n"
+            "dist.destroy_process_group(); print('OK')\n")
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]

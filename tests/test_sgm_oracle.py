@@ -46,7 +46,7 @@ def test_fixture():
     assert np.array_equal(cl, g["census_left"]) and np.array_equal(cr, g["census_right"])
     C = pysgm.cost(cl, cr, D)
     assert np.array_equal(C[g["rows"]], g["cost_rows"])
-    for i, k in ((0, "path0"), (1, "path1")):
+    for i, k in ((i, f"path{i}") for i in range(8)):        # all eight aggregation paths are pinned
         L = pysgm.aggregate(C, P1, P2, i)
         assert np.array_equal(L[g["rows"]], g[k + "_rows"]) and np.array_equal(L.astype(np.uint32).sum(axis=2), g[k + "_sum"])
     disp, S = pysgm.compute(g["left"], g["right"], D, P1, P2, want_S=True)
