@@ -210,6 +210,14 @@ def main():
         sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: librccl prints a version banner on file descriptor 1 when its first communicator
+    # comes up, so descriptor 1 is pointed at stderr for the whole run and the line goes out through a saved copy of the real one
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
     import numpy as np
     import torch
@@ -253,8 +261,8 @@ def main():
     if args.launch_check:
         counts = mdist.gather_counts(torch.tensor([lo, hi], dtype=torch.int32))
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": "gloo", "camera_width": cam_s.width,
-                              "cluster_size": prm_s.cluster_size, "shards": [c.tolist() for c in counts]}))
+            emit({"launch_check": True, "n_gpus": world, "backend": "gloo", "camera_width": cam_s.width,
+                              "cluster_size": prm_s.cluster_size, "shards": [c.tolist() for c in counts]})
         if group_up:
             dist.barrier()
             dist.destroy_process_group()
@@ -407,7 +415,7 @@ def main():
         }
         if c5 is not None:
             line["config5"] = c5
-        print(json.dumps(line))
+        emit(line)
     ctx.close()
     if group_up:
         dist.barrier()
