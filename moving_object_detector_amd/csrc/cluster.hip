@@ -28,6 +28,7 @@
 #include "mod_launch.h"
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include "introsort_emul.h"
 #include "../../include/mod_sf.h"
 
@@ -587,6 +588,370 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 #undef COUNT
   if (tid == 0) hdr[1] = s_nreq;                   // s_nreq is final: the barrier after the request loop has passed (hdr[0] is 1 already)
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_ccl_rows — the tile stage for neighbor_distance <= 4 (the reference's default is 4, Clusterer.cfg:11): the same contract as
+// k_ccl_tile (parent[p] = tile root for every dynamic pixel of the tile, root bits, one (size, first_edge_key) record per tile
+// root, one link request per connected group of halo cells that a tile component reaches), a different decomposition.
+//
+// k_ccl_tile's duration is its instruction issue time (profiles/r02_pmc_notes.md): a per-pixel union-find in LDS, four waves
+// and nine barriers per tile, ~17 000 wave-instructions per active tile, most of them issued for a handful of lanes.  Here
+//   * ONE wave owns a tile: lane = column, a grid row (tile row or one of the 4 halo rows above) is one register; no barrier,
+//     no atomic, no pointer chasing.  LDS holds the grid (depth and 16-bit labels, pitch 68 = 4 left-halo columns + 64) only so
+//     that a row can be fetched by a loop index and read shifted by k columns (the window's x - k) without lane shuffles;
+//   * a LINK MASK per window position is one v_sub + one v_cmp writing a 64-bit scalar mask, combined with the dynamic bits of the
+//     two rows on the scalar unit: E = M[r] & (M[r - dv] << k) & gate.  "Has an up-left edge" (first_edge_key) is the OR of those;
+//   * labels are the smallest cell id of the component: runs start with their first cell's id (closed form from the mask),
+//     a DOWN sweep (row r takes the minimum of the labels straight above its vertically linked pixels, then every run is
+//     levelled with a segmented min-scan over DPP row shifts / row_bcast, predicated by scalar masks derived from the run bits)
+//     and an UP sweep repeat until a sweep changes nothing: a convex blob needs one of each;
+//   * the remaining 22 window positions only VERIFY in the common case (labels already equal, every pixel has its edge): a row
+//     whose window rows all carry its one label and whose pixels all have an up-left edge costs a few scalar instructions;
+//     a link between different labels lowers both ends and sends the tile through the sweeps again (rare);
+//   * halo cells are nodes like any other (ids carry bit 15, so a component's smallest id is a tile pixel when it has one):
+//     the rows above take part in the sweeps, the 4 columns to the left live in LDS only and are reached by the window pass.
+// Semantics as clusterer_nodelet.cpp:56-83,186-219 (window = up-left quadrant, depth gate `!(|dz| > th)`, NaN links).
+namespace rows {
+constexpr int TH = 16, HL = 4, PH = TH + HL, PW = 64 + HL;
+constexpr uint32_t kNoLabel = 0xFFFFu;
+
+// value known to be the same in all lanes -> scalar registers
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// per lane: bit `lane` of the scalar mask m ? a : b   (one v_cndmask with an SGPR-pair condition, no per-lane shift)
+__device__ __forceinline__ uint32_t sel(uint64_t m, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
+#define ROWS_DPP(v, ctrl, rowmask) (uint32_t) __builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, rowmask, 0xF, false)
+
+// Every lane of a run takes the run's minimum.  L: bit x = lane x is linked to lane x - 1 (bit 0 is clear); lanes outside runs
+// keep their value.  Forward inclusive min-scan (row_shr 1, 2, 4, 8 inside the 16-lane rows, row_bcast 15 / 31 across them), each
+// step predicated by "the link bits between source and destination are all set" — masks made on the scalar unit by doubling —
+// then the same backwards (row_shl, and v_readlane of lanes 48 / 32 / 16 for the row boundaries, top row first).
+__device__ __forceinline__ uint32_t seg_run_min(uint32_t v, uint64_t L) {
+  constexpr uint64_t R1 = 0xFFFEFFFEFFFEFFFEull, R2 = 0xFFFCFFFCFFFCFFFCull, R4 = 0xFFF0FFF0FFF0FFF0ull, R8 = 0xFF00FF00FF00FF00ull;
+  {
+    const uint64_t p2 = L & (L << 1), p4 = p2 & (p2 << 2), p8 = p4 & (p4 << 4);
+    uint32_t t;
+    t = ROWS_DPP(v, 0x111, 0xF); v = sel(L & R1, min(v, t), v);
+    t = ROWS_DPP(v, 0x112, 0xF); v = sel(p2 & R2, min(v, t), v);
+    t = ROWS_DPP(v, 0x114, 0xF); v = sel(p4 & R4, min(v, t), v);
+    t = ROWS_DPP(v, 0x118, 0xF); v = sel(p8 & R8, min(v, t), v);
+    // A: all link bits from the start of the lane's 16-lane row up to the lane are set
+    uint64_t A = L & ((L << 1) | ~R1);
+    A &= (A << 2) | ~R2; A &= (A << 4) | ~R4; A &= (A << 8) | ~R8;
+    t = ROWS_DPP(v, 0x142, 0xA); v = sel(A & 0xFFFF0000FFFF0000ull, min(v, t), v);             // row_bcast:15 into rows 1 and 3
+    const uint64_t a31 = (A & 0x0000FFFF00000000ull) | (((A >> 47) & 1ull) ? (A & 0xFFFF000000000000ull) : 0ull);
+    t = ROWS_DPP(v, 0x143, 0xC); v = sel(a31, min(v, t), v);                                   // row_bcast:31 into rows 2 and 3
+  }
+  {
+    constexpr uint64_t S1 = 0x7FFF7FFF7FFF7FFFull, S2 = 0x3FFF3FFF3FFF3FFFull, S4 = 0x0FFF0FFF0FFF0FFFull, S8 = 0x00FF00FF00FF00FFull;
+    const uint64_t Rr = L >> 1;                          // bit x: lane x is linked to lane x + 1
+    const uint64_t q2 = Rr & (Rr >> 1), q4 = q2 & (q2 >> 2), q8 = q4 & (q4 >> 4);
+    uint32_t t;
+    t = ROWS_DPP(v, 0x101, 0xF); v = sel(Rr & S1, min(v, t), v);
+    t = ROWS_DPP(v, 0x102, 0xF); v = sel(q2 & S2, min(v, t), v);
+    t = ROWS_DPP(v, 0x104, 0xF); v = sel(q4 & S4, min(v, t), v);
+    t = ROWS_DPP(v, 0x108, 0xF); v = sel(q8 & S8, min(v, t), v);
+    // B: all link bits from the lane to the first lane of the next 16-lane row are set
+    uint64_t B = Rr & ((Rr >> 1) | ~S1);
+    B &= (B >> 2) | ~S2; B &= (B >> 4) | ~S4; B &= (B >> 8) | ~S8;
+    uint32_t s;
+    s = (uint32_t)__builtin_amdgcn_readlane((int)v, 48); v = sel(B & 0x0000FFFF00000000ull, min(v, s), v);
+    s = (uint32_t)__builtin_amdgcn_readlane((int)v, 32); v = sel(B & 0x00000000FFFF0000ull, min(v, s), v);
+    s = (uint32_t)__builtin_amdgcn_readlane((int)v, 16); v = sel(B & 0x000000000000FFFFull, min(v, s), v);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
+  __shared__ float Z[PH * PW];            // depth of the grid: row r = image row y0 - 4 + r, column j = image column x0 - 4 + j
+  __shared__ uint16_t LAB[PH * PW];       // labels: cell id (r * PW + j) of the smallest cell of the set, | kHaloBit for halo cells
+  __shared__ uint64_t sM[PH], sL1[PH], sV[PH], sU[PH], sRB[PH];   // per row: dynamic bits / linked to the left / linked upwards / has an up-left edge / tile roots
+  __shared__ uint32_t sMH[PH];            // dynamic bits of the 4 left-halo columns (bit j = column x0 - 4 + j)
+  const int lane = threadIdx.x;
+  const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
+  const int MW = c.mask_words, n = c.n;                 // n <= 4
+  const size_t N = (size_t)c.W * c.H, fN = (size_t)f * N;
+  int *hdr = a.tilehdr + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * 2;
+  if (__builtin_amdgcn_readfirstlane(hdr[0]) == 0) return;          // no dynamic pixel in the tile: one scalar load
+  const float th = c.depth_th;
+#ifdef MOD_PHASE_COUNTERS   // diagnostic build only (make PHASE_COUNTERS=1, tools/dbg_rows_counters.py): event counts and cycles per tile
+  unsigned long long rc_[16] = {};
+  const unsigned long long rt0_ = clock64();
+  unsigned long long rt1_ = rt0_;
+#define RCOUNT(i, v) rc_[i] += (unsigned long long)(v);
+#define RSTAMP(i) { const unsigned long long t_ = clock64(); rc_[i] += t_ - rt1_; rt1_ = t_; }
+#else
+#define RCOUNT(i, v)
+#define RSTAMP(i)
+#endif
+  // ---- all HBM reads in one round trip: mask words (lane r reads row r's), depth rows ----
+  uint64_t q0 = 0ull;
+  uint32_t qh = 0u;
+  if (lane < PH) {
+    const int gy = y0 - HL + lane;
+    const bool inrow = gy >= 0 && gy < c.H && lane >= HL - n;
+    const uint64_t *mr = a.mask + ((size_t)f * c.H + (inrow ? gy : 0)) * MW;
+    q0 = inrow ? mr[wi] : 0ull;
+    const uint64_t qL = (inrow && wi > 0) ? mr[wi - 1] : 0ull;
+    qh = (uint32_t)(qL >> 60) & (0xFu << (HL - n)) & 0xFu;          // only the n nearest columns can be window cells
+    sM[lane] = q0; sMH[lane] = qh;
+  }
+  float zr[PH], zh[PH];
+  {
+    const int xc = min(x0 + lane, c.W - 1), xh = max(x0 - HL + min(lane, HL - 1), 0);
+#pragma unroll
+    for (int r = 0; r < PH; r++) {
+      const int gy = min(max(y0 - HL + r, 0), c.H - 1);
+      const size_t rowp = fN + (size_t)gy * c.W;
+      zr[r] = a.z[rowp + xc];
+      zh[r] = a.z[rowp + xh];
+    }
+  }
+  // ---- setup: grid into LDS; link masks of the two pre-linked positions (left, up); labels = first cell of the pixel's run ----
+  {
+    uint64_t Mprev = 0ull;
+    float zprev = 0.0f;
+#pragma unroll
+    for (int r = 0; r < PH; r++) {
+      const uint64_t Mr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q0 >> 32), r) << 32) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q0, r);
+      const uint32_t Hr = (uint32_t)__builtin_amdgcn_readlane((int)qh, r);
+      const float zc = zr[r];
+      Z[r * PW + HL + lane] = zc;
+      if (lane < HL) {
+        Z[r * PW + lane] = zh[r];
+        LAB[r * PW + lane] = (uint16_t)(((Hr >> lane) & 1u) ? (uint32_t)(kHaloBit | (r * PW + lane)) : kNoLabel);
+      }
+      uint64_t L1 = 0ull, Vr = 0ull;
+      uint32_t lab = kNoLabel;
+      if (Mr) {                                                      // wave-uniform
+        const float zl = __uint_as_float(ROWS_DPP(__float_as_uint(zc), 0x138, 0xF));    // wave_shr:1
+        L1 = Mr & (Mr << 1) & __ballot(!(fabsf(zc - zl) > th));      // depthDiff gate (clusterer_nodelet.cpp:194); a NaN links
+        if (Mprev) Vr = Mr & Mprev & __ballot(!(fabsf(zc - zprev) > th));
+        const uint64_t starts = Mr & ~L1;
+        const int s = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
+        if ((Mr >> lane) & 1ull) lab = (uint32_t)(r * PW + HL + s) | (r < HL ? (uint32_t)kHaloBit : 0u);
+      }
+      LAB[r * PW + HL + lane] = (uint16_t)lab;
+      if (lane == 0) { sL1[r] = L1; sV[r] = Vr; sU[r] = L1 | Vr; }
+      Mprev = Mr; zprev = zc;
+    }
+  }
+  asm volatile("" ::: "memory");           // one wave: its LDS operations execute in order; only the compiler must not reorder them
+  RSTAMP(12)
+  // ---- sweeps ----
+  auto sweep = [&](const bool down, const bool force) -> bool {
+    bool changed = false;
+    uint32_t carry = kNoLabel;
+#pragma unroll 1
+    for (int i = 0; i < PH; i++) {
+      const int r = down ? i : PH - 1 - i;
+      const uint64_t M = uni64(sM[r]);
+      if (M == 0) continue;                                          // no link can involve this row: the carry is not looked at
+      RCOUNT(3, 1)
+      const uint32_t cur = LAB[r * PW + HL + lane];
+      const uint64_t V = (i == 0) ? 0ull : uni64(sV[down ? r : r + 1]);
+      uint32_t nv = cur;
+      if (V) nv = min(cur, sel(V, carry, kNoLabel));
+      if (force || __ballot(nv != cur)) {
+        const uint64_t L = uni64(sL1[r]);
+        if (L) {
+          const uint32_t pv = ROWS_DPP(nv, 0x138, 0xF);
+          if (__ballot(nv != pv) & L) { nv = seg_run_min(nv, L); RCOUNT(4, 1) }
+        }
+        if (__ballot(nv != cur)) {
+          LAB[r * PW + HL + lane] = (uint16_t)nv;
+          changed = true;
+        }
+      }
+      carry = nv;
+      asm volatile("" ::: "memory");
+    }
+    return changed;
+  };
+  // ---- the other window positions: verify, collect "has an up-left edge", unite where labels still differ ----
+  auto window_pass = [&]() -> bool {
+    bool changed = false;
+#pragma unroll 1
+    for (int r = HL; r < PH; r++) {
+      const uint64_t M = uni64(sM[r]);
+      if (M == 0) continue;
+      RCOUNT(5, 1)
+      uint64_t U = uni64(sU[r]);
+      uint32_t cur = LAB[r * PW + HL + lane];
+      const uint32_t cur0 = cur;
+      const float zp = Z[r * PW + HL + lane];
+#pragma unroll 1
+      for (int dv = 0; dv <= n; dv++) {
+        const int qr = r - dv;
+        const uint64_t Mq = uni64(sM[qr]);
+        const uint32_t Hq = uni32(sMH[qr]);
+        if (Mq == 0 && Hq == 0) continue;
+#pragma unroll 1
+        for (int k = (dv == 0 ? 1 : 0); k <= n; k++) {
+          // candidates: pixel (r, x) and cell (r - dv, x - k) both dynamic; lanes x < k look at the left-halo columns
+          const uint64_t C = M & ((Mq << k) | (uint64_t)(Hq >> (HL - k)));
+          if (C == 0) continue;
+          RCOUNT(6, 1)
+          const int qi = qr * PW + HL + lane - k;
+          const uint32_t lq = LAB[qi];
+          const uint64_t differ = __ballot(lq != cur) & C;
+          if (differ == 0 && (C & ~U) == 0) continue;                 // same labels, and every candidate pixel has its edge already
+          RCOUNT(7, 1)
+          const float zq = Z[qi];
+          const uint64_t E = C & __ballot(!(fabsf(zp - zq) > th));
+          U |= E;
+          const uint64_t D = E & differ;
+          if (D) {                                                    // a link between two labels: both ends take the smaller
+            RCOUNT(8, 1)
+            if ((D >> lane) & 1ull) {
+              const uint32_t m = min(cur, lq);
+              if (lq != m) LAB[qi] = (uint16_t)m;
+              cur = m;
+            }
+            changed = true;
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+      if (cur < cur0) LAB[r * PW + HL + lane] = (uint16_t)cur;        // per lane: a cell lowered through LDS by another lane keeps that value
+      if (lane == 0) sU[r] = U;
+      asm volatile("" ::: "memory");
+    }
+    return changed;
+  };
+  {
+    bool force = false;
+    while (true) {
+      // down / up until a sweep finds nothing to change.  The first down sweep of a round does not count: after the window pass has
+      // lowered single cells, rows ABOVE them are reached only by the up sweep — and the links among the halo rows are verified by
+      // nobody else (the window pass looks at the windows of tile pixels only).
+      bool first = true;
+      RCOUNT(1, 1)
+      while (true) {
+        const bool d = sweep(true, force);
+        RCOUNT(2, 1)
+        force = false;
+        if (!d && !first) break;
+        first = false;
+        RCOUNT(2, 1)
+        if (!sweep(false, false)) break;
+      }
+      RSTAMP(13)
+      const bool w_ = window_pass();
+      RSTAMP(14)
+      if (!w_) break;
+      force = true;                       // labels were lowered cell by cell: runs must be levelled again
+    }
+  }
+  // ---- publish: parent[p] = tile root, root bits ----
+#pragma unroll 1
+  for (int r = HL; r < PH; r++) {
+    const int gy = y0 + r - HL;
+    const uint64_t M = uni64(sM[r]);
+    uint64_t rb = 0ull;
+    if (M) {
+      const uint32_t cur = LAB[r * PW + HL + lane];
+      const bool dyn = (M >> lane) & 1ull;
+      if (dyn) {
+        const int rr = (int)cur / PW, cc = (int)cur - rr * PW;
+        const int rg = (y0 + rr - HL) * c.W + x0 + cc - HL;
+        if (MOD_CHECK(a, rr >= HL && rr < PH && cc >= HL && cc < PW && rg >= 0 && (size_t)rg < N, 13))
+          a.parent[fN + (size_t)gy * c.W + x0 + lane] = rg;
+      }
+      rb = __ballot(dyn && cur == (uint32_t)(r * PW + HL + lane));
+    }
+    if (lane == 0) { sRB[r] = rb; if (gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + wi] = rb; }
+  }
+  asm volatile("" ::: "memory");
+  // ---- per tile root: member count and first_edge_key (smallest raster index of a member with an up-left edge) ----
+#pragma unroll 1
+  for (int r0 = HL; r0 < PH; r0++) {
+    uint64_t rb = uni64(sRB[r0]);
+    while (rb) {                                                     // wave-uniform
+      const int b = __builtin_ctzll(rb);
+      rb &= rb - 1ull;
+      const uint32_t R = (uint32_t)(r0 * PW + HL + b);
+      RCOUNT(9, 1)
+      int size = 0, key = kKeyNone;
+#pragma unroll 1
+      for (int r = r0; r < PH; r++) {                                // the root is the set's first cell in raster order
+        const uint64_t M = uni64(sM[r]);
+        if (M == 0) continue;
+        const uint64_t eq = __ballot(LAB[r * PW + HL + lane] == R) & M;
+        size += __popcll((unsigned long long)eq);
+        if (key == kKeyNone) {
+          const uint64_t e = eq & uni64(sU[r]);
+          if (e) key = (y0 + r - HL) * c.W + x0 + __builtin_ctzll(e);
+        }
+      }
+      if (lane == 0) {
+        const size_t rg = fN + (size_t)(y0 + r0 - HL) * c.W + x0 + b;
+        a.rsize[rg] = size; a.rkey[rg] = key;
+      }
+    }
+  }
+  // ---- link requests: a halo cell that ended up in a set with a tile pixel (its label is a tile cell) belongs to another tile,
+  // whose root is not known yet -> (halo pixel, tile root) for k_ccl_link; a cell whose left / upper neighbour is a halo cell of
+  // the same set with a direct link leaves it to that neighbour (that link is one the tile owning the cell sees itself) ----
+  int nreq = 0;
+  uint2 *req = a.requests + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * a.req_cap;
+  auto emit = [&](bool want, int hg, uint32_t lab) {
+    const uint64_t wb = __ballot(want);
+    if (wb == 0) return;
+    if (want) {
+      const int slot = nreq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wb, 0u));
+      const int rr = (int)lab / PW, cc = (int)lab - rr * PW;
+      const int rg = (y0 + rr - HL) * c.W + x0 + cc - HL;
+      if (MOD_CHECK(a, slot >= 0 && slot < a.req_cap, 12) && MOD_CHECK(a, rg >= 0 && (size_t)rg < N && hg >= 0 && (size_t)hg < N, 13))
+        req[slot] = make_uint2((uint32_t)hg, (uint32_t)rg);
+    }
+    nreq += __popcll((unsigned long long)wb);
+  };
+#pragma unroll 1
+  for (int r = HL - n; r < HL; r++) {                                // the rows above the tile, columns x0 .. x0 + 63
+    const uint64_t M = uni64(sM[r]);
+    if (M == 0) continue;
+    const uint32_t lab = LAB[r * PW + HL + lane];
+    const uint64_t covered = uni64(sL1[r]) | uni64(sV[r]);
+    const bool want = ((M & ~covered) >> lane) & 1ull && !(lab & kHaloBit);
+    emit(want, (y0 - HL + r) * c.W + x0 + lane, lab);
+  }
+#pragma unroll 1
+  for (int i0 = 0; i0 < PH * HL; i0 += 64) {                         // the 4 columns to the left, all 20 rows
+    const int i = i0 + lane, r = min(i >> 2, PH - 1), j = i & 3;
+    bool want = false;
+    uint32_t lab = kNoLabel;
+    if (i < PH * HL && ((sMH[r] >> j) & 1u)) {
+      lab = LAB[r * PW + j];
+      if (!(lab & kHaloBit)) {
+        const float zme = Z[r * PW + j];
+        const bool cov_up = r > 0 && ((sMH[r - 1] >> j) & 1u) && LAB[(r - 1) * PW + j] == lab && !(fabsf(zme - Z[(r - 1) * PW + j]) > th);
+        const bool cov_left = j > 0 && ((sMH[r] >> (j - 1)) & 1u) && LAB[r * PW + j - 1] == lab && !(fabsf(zme - Z[r * PW + j - 1]) > th);
+        want = !(cov_up || cov_left);
+      }
+    }
+    emit(want, (y0 - HL + r) * c.W + x0 - HL + j, lab);
+  }
+  if (lane == 0) hdr[1] = nreq;
+#ifdef MOD_PHASE_COUNTERS
+  RSTAMP(15)
+  rc_[0] = 1; rc_[10] = clock64() - rt0_; rc_[11] = nreq;
+  if ((c.debug & 128) && lane == 0)
+    for (int i = 0; i < 16; i++) atomicAdd(&a.dbg[i], rc_[i]);
+#endif
+#undef RCOUNT
+#undef RSTAMP
+}
+#undef ROWS_DPP
+}  // namespace rows
 
 // Tile headers from a mask plane that did not come out of the fused scene-flow kernel (mod_cluster_dev): {1, 0} for tiles with a
 // dynamic pixel, {0, 0} for the others.  One thread per tile.
@@ -1466,6 +1831,10 @@ static dim3 tile_grid(const DevCam &c, int frames) { return dim3(c.mask_words, (
 
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 block(64, kTileWaves, 1), tgrid = tile_grid(c, frames);
+  // neighbor_distance <= 4 (the reference's default is 4): one wave per tile (k_ccl_rows); MOD_TILE_KERNEL=unionfind selects the
+  // four-wave LDS union-find kernel for A/B runs, which also serves the wider windows
+  static const bool use_rows = [] { const char *e = std::getenv("MOD_TILE_KERNEL"); return !(e && std::string(e) == "unionfind"); }();
+  if (c.n <= 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows, tgrid, dim3(64, 1, 1), 0, s, c, a); return; }
   if (c.n == 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, true>), tgrid, block, 0, s, c, a);
   else if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, false>), tgrid, block, 0, s, c, a);
   else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves, false>), tgrid, block, 0, s, c, a);
