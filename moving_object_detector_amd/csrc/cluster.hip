@@ -669,14 +669,13 @@ __device__ __forceinline__ uint32_t seg_run_min(uint32_t v, uint64_t L) {
   return v;
 }
 
+template <bool N4>
 __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
   __shared__ float Z[PH * PW];            // depth of the grid: row r = image row y0 - 4 + r, column j = image column x0 - 4 + j
   __shared__ uint16_t LAB[PH * PW];       // labels: cell id (r * PW + j) of the smallest cell of the set, | kHaloBit for halo cells
-  __shared__ uint64_t sM[PH], sL1[PH], sV[PH], sU[PH], sRB[PH];   // per row: dynamic bits / linked to the left / linked upwards / has an up-left edge / tile roots
-  __shared__ uint32_t sMH[PH];            // dynamic bits of the 4 left-halo columns (bit j = column x0 - 4 + j)
   const int lane = threadIdx.x;
   const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
-  const int MW = c.mask_words, n = c.n;                 // n <= 4
+  const int MW = c.mask_words, n = N4 ? 4 : c.n;        // n <= 4; the default 4 has its own instance (constant window bounds)
   const size_t N = (size_t)c.W * c.H, fN = (size_t)f * N;
   int *hdr = a.tilehdr + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * 2;
   if (__builtin_amdgcn_readfirstlane(hdr[0]) == 0) return;          // no dynamic pixel in the tile: one scalar load
@@ -691,18 +690,30 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
 #define RCOUNT(i, v)
 #define RSTAMP(i)
 #endif
+  // Per-row scalars (dynamic bits, link masks, ...) live in VGPR LANES: lane r of these registers belongs to grid row r.  A row's
+  // value is fetched with v_readlane (lane index in an SGPR: the row loops stay rolled) — no LDS round trip, which is what a
+  // single wave cannot hide.
+  uint32_t mLlo = 0, mLhi = 0, mVlo = 0, mVhi = 0, mUlo = 0, mUhi = 0, mRlo = 0, mRhi = 0;
+  auto rd32 = [&](uint32_t v, int r) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, r); };
+  auto rd64 = [&](uint32_t lo, uint32_t hi, int r) -> uint64_t { return ((uint64_t)rd32(hi, r) << 32) | (uint64_t)rd32(lo, r); };
+  // (no writelane builtin in this compiler; value and lane index are scalars.  The s_nop covers the wait states a VALU-written
+  // SGPR needs before it may select a lane — inline asm is opaque to the hazard recogniser)
+  auto wr32 = [&](uint32_t &v, int r, uint32_t x) {   // one SGPR operand per VALU instruction: the lane index goes through M0 (saved / restored)
+    uint32_t keep;
+    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(v), "=&s"(keep) : "s"(x), "s"(r));
+  };
   // ---- all HBM reads in one round trip: mask words (lane r reads row r's), depth rows ----
   uint64_t q0 = 0ull;
-  uint32_t qh = 0u;
+  uint32_t mH = 0u;                                                  // dynamic bits of the 4 left-halo columns (bit j = column x0 - 4 + j)
   if (lane < PH) {
     const int gy = y0 - HL + lane;
     const bool inrow = gy >= 0 && gy < c.H && lane >= HL - n;
     const uint64_t *mr = a.mask + ((size_t)f * c.H + (inrow ? gy : 0)) * MW;
     q0 = inrow ? mr[wi] : 0ull;
     const uint64_t qL = (inrow && wi > 0) ? mr[wi - 1] : 0ull;
-    qh = (uint32_t)(qL >> 60) & (0xFu << (HL - n)) & 0xFu;          // only the n nearest columns can be window cells
-    sM[lane] = q0; sMH[lane] = qh;
+    mH = (uint32_t)(qL >> 60) & (0xFu << (HL - n)) & 0xFu;          // only the n nearest columns can be window cells
   }
+  const uint32_t mMlo = (uint32_t)q0, mMhi = (uint32_t)(q0 >> 32);   // dynamic bits of the 64 tile columns
   float zr[PH], zh[PH];
   {
     const int xc = min(x0 + lane, c.W - 1), xh = max(x0 - HL + min(lane, HL - 1), 0);
@@ -720,48 +731,52 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
     float zprev = 0.0f;
 #pragma unroll
     for (int r = 0; r < PH; r++) {
-      const uint64_t Mr = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q0 >> 32), r) << 32) |
-                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q0, r);
-      const uint32_t Hr = (uint32_t)__builtin_amdgcn_readlane((int)qh, r);
+      const uint64_t Mr = rd64(mMlo, mMhi, r);
+      const uint32_t Hr = rd32(mH, r);
       const float zc = zr[r];
       Z[r * PW + HL + lane] = zc;
       if (lane < HL) {
         Z[r * PW + lane] = zh[r];
         LAB[r * PW + lane] = (uint16_t)(((Hr >> lane) & 1u) ? (uint32_t)(kHaloBit | (r * PW + lane)) : kNoLabel);
       }
-      uint64_t L1 = 0ull, Vr = 0ull;
       uint32_t lab = kNoLabel;
       if (Mr) {                                                      // wave-uniform
         const float zl = __uint_as_float(ROWS_DPP(__float_as_uint(zc), 0x138, 0xF));    // wave_shr:1
-        L1 = Mr & (Mr << 1) & __ballot(!(fabsf(zc - zl) > th));      // depthDiff gate (clusterer_nodelet.cpp:194); a NaN links
-        if (Mprev) Vr = Mr & Mprev & __ballot(!(fabsf(zc - zprev) > th));
+        const uint64_t L1 = Mr & (Mr << 1) & __ballot(!(fabsf(zc - zl) > th));         // depthDiff gate (clusterer_nodelet.cpp:194); a NaN links
+        const uint64_t Vr = Mprev ? (Mr & Mprev & __ballot(!(fabsf(zc - zprev) > th))) : 0ull;
         const uint64_t starts = Mr & ~L1;
         const int s = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
         if ((Mr >> lane) & 1ull) lab = (uint32_t)(r * PW + HL + s) | (r < HL ? (uint32_t)kHaloBit : 0u);
+        wr32(mLlo, r, (uint32_t)L1); wr32(mLhi, r, (uint32_t)(L1 >> 32));
+        wr32(mVlo, r, (uint32_t)Vr); wr32(mVhi, r, (uint32_t)(Vr >> 32));
+        wr32(mUlo, r, (uint32_t)(L1 | Vr)); wr32(mUhi, r, (uint32_t)((L1 | Vr) >> 32));
       }
       LAB[r * PW + HL + lane] = (uint16_t)lab;
-      if (lane == 0) { sL1[r] = L1; sV[r] = Vr; sU[r] = L1 | Vr; }
       Mprev = Mr; zprev = zc;
     }
   }
   asm volatile("" ::: "memory");           // one wave: its LDS operations execute in order; only the compiler must not reorder them
   RSTAMP(12)
-  // ---- sweeps ----
+  // ---- sweeps: row r takes the labels straight above (below) its vertically linked pixels, then its runs are levelled ----
   auto sweep = [&](const bool down, const bool force) -> bool {
     bool changed = false;
     uint32_t carry = kNoLabel;
+    const int step = down ? 1 : -1;
+    int r = down ? 0 : PH - 1;
+    uint32_t nextv = LAB[r * PW + HL + lane];
 #pragma unroll 1
-    for (int i = 0; i < PH; i++) {
-      const int r = down ? i : PH - 1 - i;
-      const uint64_t M = uni64(sM[r]);
+    for (int i = 0; i < PH; i++, r += step) {
+      const uint32_t cur = nextv;
+      if (i + 1 < PH) nextv = LAB[(r + step) * PW + HL + lane];      // the next row's labels are on their way while this row is worked on
+      const uint64_t M = rd64(mMlo, mMhi, r);
       if (M == 0) continue;                                          // no link can involve this row: the carry is not looked at
       RCOUNT(3, 1)
-      const uint32_t cur = LAB[r * PW + HL + lane];
-      const uint64_t V = (i == 0) ? 0ull : uni64(sV[down ? r : r + 1]);
+      const int vr = down ? r : r + 1;
+      const uint64_t V = (i == 0) ? 0ull : rd64(mVlo, mVhi, vr);
       uint32_t nv = cur;
       if (V) nv = min(cur, sel(V, carry, kNoLabel));
       if (force || __ballot(nv != cur)) {
-        const uint64_t L = uni64(sL1[r]);
+        const uint64_t L = rd64(mLlo, mLhi, r);
         if (L) {
           const uint32_t pv = ROWS_DPP(nv, 0x138, 0xF);
           if (__ballot(nv != pv) & L) { nv = seg_run_min(nv, L); RCOUNT(4, 1) }
@@ -772,8 +787,8 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
         }
       }
       carry = nv;
-      asm volatile("" ::: "memory");
     }
+    asm volatile("" ::: "memory");
     return changed;
   };
   // ---- the other window positions: verify, collect "has an up-left edge", unite where labels still differ ----
@@ -781,48 +796,73 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
     bool changed = false;
 #pragma unroll 1
     for (int r = HL; r < PH; r++) {
-      const uint64_t M = uni64(sM[r]);
+      const uint64_t M = rd64(mMlo, mMhi, r);
       if (M == 0) continue;
       RCOUNT(5, 1)
-      uint64_t U = uni64(sU[r]);
+      uint64_t U = rd64(mUlo, mUhi, r);
       uint32_t cur = LAB[r * PW + HL + lane];
       const uint32_t cur0 = cur;
-      const float zp = Z[r * PW + HL + lane];
-#pragma unroll 1
-      for (int dv = 0; dv <= n; dv++) {
-        const int qr = r - dv;
-        const uint64_t Mq = uni64(sM[qr]);
-        const uint32_t Hq = uni32(sMH[qr]);
-        if (Mq == 0 && Hq == 0) continue;
-#pragma unroll 1
-        for (int k = (dv == 0 ? 1 : 0); k <= n; k++) {
-          // candidates: pixel (r, x) and cell (r - dv, x - k) both dynamic; lanes x < k look at the left-halo columns
-          const uint64_t C = M & ((Mq << k) | (uint64_t)(Hq >> (HL - k)));
+      // the labels of all window cells in ONE round trip (cell (r - dv, x - k) for lane x; lanes x < k reach the left-halo columns)
+      uint32_t lq[5][5];
+#pragma unroll
+      for (int dv = 0; dv <= 4; dv++)
+#pragma unroll
+        for (int k = 0; k <= 4; k++)
+          if ((dv | k) != 0 && (N4 || (dv <= n && k <= n))) lq[dv][k] = LAB[(r - dv) * PW + HL + lane - k];
+      uint64_t Mq[5];
+      uint32_t Hq[5];
+#pragma unroll
+      for (int dv = 0; dv <= 4; dv++) { Mq[dv] = (N4 || dv <= n) ? rd64(mMlo, mMhi, r - dv) : 0ull; Hq[dv] = (N4 || dv <= n) ? rd32(mH, r - dv) : 0u; }
+      // candidates of a position: pixel (r, x) and cell (r - dv, x - k) both dynamic
+      auto cand = [&](int dv, int k) -> uint64_t { return M & ((Mq[dv] << k) | (uint64_t)(Hq[dv] >> (HL - k))); };
+      // pass 1 (no depth read): which positions still matter — a candidate pair with two labels, or a pixel still lacking its edge
+      uint32_t need = 0;
+#pragma unroll
+      for (int dv = 0; dv <= 4; dv++)
+#pragma unroll
+        for (int k = 0; k <= 4; k++) {
+          if ((dv | k) == 0 || !(N4 || (dv <= n && k <= n))) continue;
+          const uint64_t C = cand(dv, k);
           if (C == 0) continue;
           RCOUNT(6, 1)
-          const int qi = qr * PW + HL + lane - k;
-          const uint32_t lq = LAB[qi];
-          const uint64_t differ = __ballot(lq != cur) & C;
-          if (differ == 0 && (C & ~U) == 0) continue;                 // same labels, and every candidate pixel has its edge already
+          if ((__ballot(lq[dv][k] != cur) & C) | (C & ~U)) need |= 1u << (dv * 5 + k);
+        }
+      if (need == 0) continue;
+      const float zp = Z[r * PW + HL + lane];
+      float zq[5][5];
+#pragma unroll
+      for (int dv = 0; dv <= 4; dv++)
+#pragma unroll
+        for (int k = 0; k <= 4; k++)
+          if ((dv | k) != 0 && (N4 || (dv <= n && k <= n))) zq[dv][k] = Z[(r - dv) * PW + HL + lane - k];
+#pragma unroll
+      for (int dv = 0; dv <= 4; dv++)
+#pragma unroll
+        for (int k = 0; k <= 4; k++) {
+          if ((dv | k) == 0 || !(N4 || (dv <= n && k <= n))) continue;
+          if (!((need >> (dv * 5 + k)) & 1u)) continue;
+          const uint64_t C = cand(dv, k);
+          const uint64_t differ = __ballot(lq[dv][k] != cur) & C;
+          if (differ == 0 && (C & ~U) == 0) continue;                 // an earlier position of this row has settled it
           RCOUNT(7, 1)
-          const float zq = Z[qi];
-          const uint64_t E = C & __ballot(!(fabsf(zp - zq) > th));
+          const uint64_t E = C & __ballot(!(fabsf(zp - zq[dv][k]) > th));
           U |= E;
-          const uint64_t D = E & differ;
-          if (D) {                                                    // a link between two labels: both ends take the smaller
+          if (E & differ) {                                           // a link between two labels: both ends take the smaller (rare)
             RCOUNT(8, 1)
-            if ((D >> lane) & 1ull) {
-              const uint32_t m = min(cur, lq);
-              if (lq != m) LAB[qi] = (uint16_t)m;
-              cur = m;
-            }
-            changed = true;
+            const int qi = (r - dv) * PW + HL + lane - k;
+            const uint32_t fresh = LAB[qi];                           // the cell as it is NOW (another lane of this row may have lowered it)
+            const uint32_t m = min(cur, fresh);
+            const bool in = (E >> lane) & 1ull;
+            const bool tgt = in && fresh != m, me = in && cur != m;
+            if (tgt) LAB[qi] = (uint16_t)m;
+            if (me) cur = m;
+            // a left-halo cell that still carried its own id has no dependants: lowering it needs no further round
+            if (__ballot(me || (tgt && !(lane < k && (fresh & kHaloBit))))) changed = true;
             asm volatile("" ::: "memory");
           }
         }
-      }
       if (cur < cur0) LAB[r * PW + HL + lane] = (uint16_t)cur;        // per lane: a cell lowered through LDS by another lane keeps that value
-      if (lane == 0) sU[r] = U;
+      wr32(mUlo, r, (uint32_t)U); wr32(mUhi, r, (uint32_t)(U >> 32));
       asm volatile("" ::: "memory");
     }
     return changed;
@@ -855,7 +895,7 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
 #pragma unroll 1
   for (int r = HL; r < PH; r++) {
     const int gy = y0 + r - HL;
-    const uint64_t M = uni64(sM[r]);
+    const uint64_t M = rd64(mMlo, mMhi, r);
     uint64_t rb = 0ull;
     if (M) {
       const uint32_t cur = LAB[r * PW + HL + lane];
@@ -867,28 +907,31 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
           a.parent[fN + (size_t)gy * c.W + x0 + lane] = rg;
       }
       rb = __ballot(dyn && cur == (uint32_t)(r * PW + HL + lane));
+      wr32(mRlo, r, (uint32_t)rb); wr32(mRhi, r, (uint32_t)(rb >> 32));
     }
-    if (lane == 0) { sRB[r] = rb; if (gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + wi] = rb; }
+    if (lane == 0 && gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + wi] = rb;
   }
-  asm volatile("" ::: "memory");
   // ---- per tile root: member count and first_edge_key (smallest raster index of a member with an up-left edge) ----
 #pragma unroll 1
   for (int r0 = HL; r0 < PH; r0++) {
-    uint64_t rb = uni64(sRB[r0]);
+    uint64_t rb = rd64(mRlo, mRhi, r0);
     while (rb) {                                                     // wave-uniform
       const int b = __builtin_ctzll(rb);
       rb &= rb - 1ull;
       const uint32_t R = (uint32_t)(r0 * PW + HL + b);
       RCOUNT(9, 1)
       int size = 0, key = kKeyNone;
+      uint32_t nextv = LAB[r0 * PW + HL + lane];
 #pragma unroll 1
       for (int r = r0; r < PH; r++) {                                // the root is the set's first cell in raster order
-        const uint64_t M = uni64(sM[r]);
+        const uint32_t v = nextv;
+        if (r + 1 < PH) nextv = LAB[(r + 1) * PW + HL + lane];
+        const uint64_t M = rd64(mMlo, mMhi, r);
         if (M == 0) continue;
-        const uint64_t eq = __ballot(LAB[r * PW + HL + lane] == R) & M;
+        const uint64_t eq = __ballot(v == R) & M;
         size += __popcll((unsigned long long)eq);
         if (key == kKeyNone) {
-          const uint64_t e = eq & uni64(sU[r]);
+          const uint64_t e = eq & rd64(mUlo, mUhi, r);
           if (e) key = (y0 + r - HL) * c.W + x0 + __builtin_ctzll(e);
         }
       }
@@ -917,28 +960,32 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
   };
 #pragma unroll 1
   for (int r = HL - n; r < HL; r++) {                                // the rows above the tile, columns x0 .. x0 + 63
-    const uint64_t M = uni64(sM[r]);
+    const uint64_t M = rd64(mMlo, mMhi, r);
     if (M == 0) continue;
     const uint32_t lab = LAB[r * PW + HL + lane];
-    const uint64_t covered = uni64(sL1[r]) | uni64(sV[r]);
-    const bool want = ((M & ~covered) >> lane) & 1ull && !(lab & kHaloBit);
+    const uint64_t covered = rd64(mLlo, mLhi, r) | rd64(mVlo, mVhi, r);
+    const bool want = (((M & ~covered) >> lane) & 1ull) && !(lab & kHaloBit);
     emit(want, (y0 - HL + r) * c.W + x0 + lane, lab);
   }
+  if (__ballot(mH != 0u)) {                                          // any dynamic cell in the 4 columns to the left (all 20 rows)?
 #pragma unroll 1
-  for (int i0 = 0; i0 < PH * HL; i0 += 64) {                         // the 4 columns to the left, all 20 rows
-    const int i = i0 + lane, r = min(i >> 2, PH - 1), j = i & 3;
-    bool want = false;
-    uint32_t lab = kNoLabel;
-    if (i < PH * HL && ((sMH[r] >> j) & 1u)) {
-      lab = LAB[r * PW + j];
-      if (!(lab & kHaloBit)) {
-        const float zme = Z[r * PW + j];
-        const bool cov_up = r > 0 && ((sMH[r - 1] >> j) & 1u) && LAB[(r - 1) * PW + j] == lab && !(fabsf(zme - Z[(r - 1) * PW + j]) > th);
-        const bool cov_left = j > 0 && ((sMH[r] >> (j - 1)) & 1u) && LAB[r * PW + j - 1] == lab && !(fabsf(zme - Z[r * PW + j - 1]) > th);
-        want = !(cov_up || cov_left);
+    for (int i0 = 0; i0 < PH * HL; i0 += 64) {
+      const int i = i0 + lane, r = min(i >> 2, PH - 1), j = i & 3;
+      // lane i needs row r's bits: mH holds them in lane r -> one cross-lane read (ds_bpermute; this loop runs twice per tile)
+      const uint32_t hr = (uint32_t)__shfl((int)mH, r), hu = (uint32_t)__shfl((int)mH, max(r - 1, 0));
+      bool want = false;
+      uint32_t lab = kNoLabel;
+      if (i < PH * HL && ((hr >> j) & 1u)) {
+        lab = LAB[r * PW + j];
+        if (!(lab & kHaloBit)) {
+          const float zme = Z[r * PW + j];
+          const bool cov_up = r > 0 && ((hu >> j) & 1u) && LAB[(r - 1) * PW + j] == lab && !(fabsf(zme - Z[(r - 1) * PW + j]) > th);
+          const bool cov_left = j > 0 && ((hr >> (j - 1)) & 1u) && LAB[r * PW + j - 1] == lab && !(fabsf(zme - Z[r * PW + j - 1]) > th);
+          want = !(cov_up || cov_left);
+        }
       }
+      emit(want, (y0 - HL + r) * c.W + x0 - HL + j, lab);
     }
-    emit(want, (y0 - HL + r) * c.W + x0 - HL + j, lab);
   }
   if (lane == 0) hdr[1] = nreq;
 #ifdef MOD_PHASE_COUNTERS
@@ -1831,10 +1878,11 @@ static dim3 tile_grid(const DevCam &c, int frames) { return dim3(c.mask_words, (
 
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 block(64, kTileWaves, 1), tgrid = tile_grid(c, frames);
-  // neighbor_distance <= 4 (the reference's default is 4): one wave per tile (k_ccl_rows); MOD_TILE_KERNEL=unionfind selects the
-  // four-wave LDS union-find kernel for A/B runs, which also serves the wider windows
-  static const bool use_rows = [] { const char *e = std::getenv("MOD_TILE_KERNEL"); return !(e && std::string(e) == "unionfind"); }();
-  if (c.n <= 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows, tgrid, dim3(64, 1, 1), 0, s, c, a); return; }
+  // MOD_TILE_KERNEL=rows selects the one-wave-per-tile kernel (k_ccl_rows, neighbor_distance <= 4): bit-exact, a third of the
+  // instructions, and SLOWER (4.6 vs 2.2 ms per 512 pairs, profiles/r03_tile_kernel_notes.md) — kept as the measured alternative
+  static const bool use_rows = [] { const char *e = std::getenv("MOD_TILE_KERNEL"); return e && std::string(e) == "rows"; }();
+  if (c.n == 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<true>, tgrid, dim3(64, 1, 1), 0, s, c, a); return; }
+  if (c.n < 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<false>, tgrid, dim3(64, 1, 1), 0, s, c, a); return; }
   if (c.n == 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, true>), tgrid, block, 0, s, c, a);
   else if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, false>), tgrid, block, 0, s, c, a);
   else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves, false>), tgrid, block, 0, s, c, a);
