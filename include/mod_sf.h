@@ -245,6 +245,25 @@ int  mod_submit_frame_host(ModContext *ctx,
                            void *cloud_aos, int32_t *labels, ModObject *objects, int32_t max_objects,
                            int32_t *ticket);
 int  mod_collect_frame_host(ModContext *ctx, int32_t ticket, int32_t *n_objects);
+
+/* Stereo images in, moving objects out: the device-resident form of stereoCallback() for BASELINE config 5
+ * (scene_flow_constructor.cpp:365-399: estimateDisparity, then construct() on construct_thread_ beside the next frame's
+ * estimators, then disparity_previous_ = disparity_now_).  The two 8-bit images go to the GPU on the copy stream, the on-GPU
+ * estimator (mod_sgm_compute_dev) writes the disparity plane straight into the pipe's ring — where it serves as `now` of this frame
+ * and as `previous` of the next — and scene flow + clustering follow on the context's stream: the disparity never crosses PCIe
+ * (mod_sgm_compute_host + mod_submit_frame_host move it there and back: two trips of 4 bytes per pixel and frame).
+ *   left / right    W*H bytes each, row-major (sensor_msgs/Image mono8); NULL = the estimator has nothing to work on:
+ *                   MOD_SKIP_NO_DISPARITY_NOW, and the next frame has no previous disparity (disparity_now_.reset(), :272-276)
+ *   sgm             estimator parameters; the camera's min / max_disparity must describe its output (0 and disparities - 1)
+ *   flow, transform, dt, cloud_aos, labels, objects, max_objects, ticket: as mod_submit_frame_host.  A frame that ends at one
+ *                   of construct()'s guards (no flow, no previous disparity, no transform) still had its disparity estimated:
+ *                   it IS the next frame's previous one (:397-398)
+ *   disparity       optional host copy of the disparity image (32FC1, -1 where no match was found), valid after collect
+ * Collected with mod_collect_frame_host like any other ticket. */
+int  mod_submit_stereo_host(ModContext *ctx, const uint8_t *left, const uint8_t *right, const ModSgmParams *sgm,
+                            const float *flow, const ModTransform *transform, double dt,
+                            void *cloud_aos, int32_t *labels, ModObject *objects, int32_t max_objects,
+                            float *disparity, int32_t *ticket);
 /* disparity_now_.reset() of a failed estimateDisparity (scene_flow_constructor.cpp:272-276): the next submit without an
  * explicit disparity_prev reports MOD_SKIP_NO_DISPARITY_PREV instead of pairing with a stale frame. */
 int  mod_forget_previous(ModContext *ctx);

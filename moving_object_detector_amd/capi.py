@@ -36,7 +36,7 @@ EXPORTS = [
     "mod_abi_version", "mod_create", "mod_destroy", "mod_last_error", "mod_set_camera", "mod_set_params",
     "mod_get_camera", "mod_get_params", "mod_synchronize", "mod_scene_flow_dev", "mod_dynamic_mask_dev",
     "mod_cluster_dev", "mod_process_dev", "mod_pack_cloud_dev", "mod_unpack_cloud_dev", "mod_process_frame_host",
-    "mod_cluster_cloud_host", "mod_submit_frame_host", "mod_collect_frame_host", "mod_forget_previous", "mod_host_malloc", "mod_host_free",
+    "mod_cluster_cloud_host", "mod_submit_frame_host", "mod_submit_stereo_host", "mod_collect_frame_host", "mod_forget_previous", "mod_host_malloc", "mod_host_free",
     "mod_malloc", "mod_free", "mod_memcpy_h2d", "mod_memcpy_d2h", "mod_set_profiling",
     "mod_get_stage_time", "mod_reset_stage_times", "mod_depth_image_dev", "mod_depth_image_host",
     "mod_sgm_census_dev", "mod_sgm_path_dev", "mod_sgm_compute_dev", "mod_sgm_compute_host",
@@ -141,6 +141,8 @@ def load(require_torch_first: bool = True):
                                          C.POINTER(i32)]
     L.mod_cluster_cloud_host.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, C.POINTER(i32)]
     L.mod_submit_frame_host.argtypes = [vp, vp, vp, vp, C.POINTER(ModTransform), C.c_double, vp, vp, vp, i32, C.POINTER(i32)]
+    L.mod_submit_stereo_host.argtypes = [vp, vp, vp, C.POINTER(ModSgmParams), vp, C.POINTER(ModTransform), C.c_double, vp, vp, vp, i32, vp,
+                                         C.POINTER(i32)]
     L.mod_collect_frame_host.argtypes = [vp, i32, C.POINTER(i32)]
     L.mod_forget_previous.argtypes = [vp]
     L.mod_host_malloc.argtypes = [vp, C.c_uint64, C.POINTER(vp)]

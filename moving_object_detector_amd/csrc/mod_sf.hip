@@ -81,6 +81,12 @@ struct ModContext {
     ModObject *user_obj[MOD_PIPELINE_DEPTH] = {};
     int32_t user_cap[MOD_PIPELINE_DEPTH] = {};
     hipEvent_t ev_in[MOD_PIPELINE_DEPTH] = {}, ev_done[MOD_PIPELINE_DEPTH] = {}, ev_out[MOD_PIPELINE_DEPTH] = {};
+    uint8_t *img[MOD_PIPELINE_DEPTH] = {};         // mod_submit_stereo_host: the slot's two 8-bit images
+    hipEvent_t ev_img[MOD_PIPELINE_DEPTH] = {};    // ... the estimator has been enqueued behind them (context stream)
+    bool img_used[MOD_PIPELINE_DEPTH] = {};
+    hipEvent_t ev_ring = nullptr;                  // last disparity plane written by kernels (stereo path)
+    bool ring_by_kernels = false;
+    int64_t dring = 0;                             // disparity planes handed out so far: plane of the next frame = dring % (DEPTH + 1)
     int64_t seq = 0;                               // frames submitted so far
     int in_flight = 0;
     bool have_prev = false;                        // dnow[(seq - 1) % (DEPTH + 1)] holds the previous frame's disparity
@@ -393,13 +399,14 @@ void mod_destroy(ModContext *c) {
     if (p.d2h) { (void)hipStreamSynchronize(p.d2h); (void)hipStreamDestroy(p.d2h); }
     for (int i = 0; i <= MOD_PIPELINE_DEPTH; i++) if (p.dnow[i]) (void)hipFree(p.dnow[i]);
     for (int i = 0; i < MOD_PIPELINE_DEPTH; i++) {
-      void *dv[] = {p.dprev[i], p.flow[i], p.planes[i], p.aos[i], p.labels[i], p.nobj[i], p.objects[i]};
+      void *dv[] = {p.dprev[i], p.flow[i], p.planes[i], p.aos[i], p.labels[i], p.nobj[i], p.objects[i], p.img[i]};
       for (void *q : dv) if (q) (void)hipFree(q);
       if (p.h_n[i]) (void)hipHostFree(p.h_n[i]);
       if (p.h_obj[i]) (void)hipHostFree(p.h_obj[i]);
-      hipEvent_t ev[] = {p.ev_in[i], p.ev_done[i], p.ev_out[i]};
+      hipEvent_t ev[] = {p.ev_in[i], p.ev_done[i], p.ev_out[i], p.ev_img[i]};
       for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     }
+    if (p.ev_ring) (void)hipEventDestroy(p.ev_ring);
   }
   for (hipStream_t q : c->b.sgm_side) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
   for (int k = 0; k < 2; k++) {
@@ -812,7 +819,9 @@ static int ensure_pipe(ModContext *c) {
     if (!p.ev_in[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_in[i], hipEventDisableTiming));
     if (!p.ev_done[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_done[i], hipEventDisableTiming));
     if (!p.ev_out[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_out[i], hipEventDisableTiming));
+    if (!p.ev_img[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_img[i], hipEventDisableTiming));
   }
+  if (!p.ev_ring) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_ring, hipEventDisableTiming));
   p.ready = true;
   return MOD_OK;
 }
@@ -833,10 +842,12 @@ int mod_submit_frame_host(ModContext *c, const float *disparity_now, const float
   if (p.in_flight >= MOD_PIPELINE_DEPTH) return fail(c, MOD_ERR_CAPACITY, "MOD_PIPELINE_DEPTH frames are already in flight");
   if ((rc = ensure_pipe(c))) return rc;
   constexpr int R = MOD_PIPELINE_DEPTH + 1;
-  const int slot = (int)(p.seq % MOD_PIPELINE_DEPTH), nowi = (int)(p.seq % R), previ = (int)((p.seq + R - 1) % R);
+  const int slot = (int)(p.seq % MOD_PIPELINE_DEPTH), nowi = (int)(p.dring % R), previ = (int)((p.dring + R - 1) % R);
   const size_t N = (size_t)c->dc.W * c->dc.H;
-  // inputs: their own stream.  dnow[nowi] was last read by frame seq - R + 1 (as its "previous"), which has been collected:
-  // at most MOD_PIPELINE_DEPTH - 1 frames are in flight at this point.
+  // inputs: their own stream.  dnow[nowi] was last read by the frame R - 1 planes ago (as its "previous"), which has been collected:
+  // at most MOD_PIPELINE_DEPTH - 1 frames are in flight at this point.  (Planes the stereo entry filled were written by kernels,
+  // and a frame it skipped took a plane without a ticket: the copy then also waits for the last of those kernels.)
+  if (p.ring_by_kernels) { HIP_TRY(c, hipStreamWaitEvent(p.h2d, p.ev_ring, 0)); p.ring_by_kernels = false; }
   HIP_TRY(c, hipMemcpyAsync(p.dnow[nowi], disparity_now, 4 * N, hipMemcpyHostToDevice, p.h2d));
   if (disparity_prev) HIP_TRY(c, hipMemcpyAsync(p.dprev[slot], disparity_prev, 4 * N, hipMemcpyHostToDevice, p.h2d));
   HIP_TRY(c, hipMemcpyAsync(p.flow[slot], flow, 8 * N, hipMemcpyHostToDevice, p.h2d));
@@ -867,7 +878,72 @@ int mod_submit_frame_host(ModContext *c, const float *disparity_now, const float
   if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, p.aos[slot], 32 * N, hipMemcpyDeviceToHost, p.d2h));
   HIP_TRY(c, hipEventRecord(p.ev_out[slot], p.d2h));
   *ticket = (int32_t)(p.seq & 0x7fffffff);
-  p.seq++; p.in_flight++; p.have_prev = true;
+  p.seq++; p.dring++; p.in_flight++; p.have_prev = true;
+  return MOD_OK;
+}
+
+int mod_submit_stereo_host(ModContext *c, const uint8_t *left, const uint8_t *right, const ModSgmParams *sgm, const float *flow,
+                           const ModTransform *transform, double dt, void *cloud_aos, int32_t *labels, ModObject *objects,
+                           int32_t max_objects, float *disparity, int32_t *ticket) {
+  int rc = check_ready(c, 1);
+  if (rc) return rc;
+  if (!ticket) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null ticket");
+  *ticket = -1;
+  ModContext::Pipe &p = c->pipe;
+  if (!left || !right) {            // estimateDisparity() has nothing to work on: disparity_now_.reset() (scene_flow_constructor.cpp:272-276)
+    p.have_prev = false;            // ... which becomes the next frame's (missing) previous disparity (:397-398)
+    return MOD_SKIP_NO_DISPARITY_NOW;
+  }
+  if ((rc = check_sgm_params(c, sgm))) return rc;
+  if (p.in_flight >= MOD_PIPELINE_DEPTH) return fail(c, MOD_ERR_CAPACITY, "MOD_PIPELINE_DEPTH frames are already in flight");
+  if ((rc = ensure_pipe(c))) return rc;
+  constexpr int R = MOD_PIPELINE_DEPTH + 1;
+  const int slot = (int)(p.seq % MOD_PIPELINE_DEPTH), nowi = (int)(p.dring % R), previ = (int)((p.dring + R - 1) % R);
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  if (!p.img[slot]) HIP_TRY(c, dalloc(&p.img[slot], 2 * c->maxN));
+  // images (and flow) on the copy stream; the slot's image buffer may still be read by the estimator of a frame that ended at a
+  // guard (it took no ticket, so nobody waited for it): the copy queues behind that estimator
+  if (p.img_used[slot]) HIP_TRY(c, hipStreamWaitEvent(p.h2d, p.ev_img[slot], 0));
+  HIP_TRY(c, hipMemcpyAsync(p.img[slot], left, N, hipMemcpyHostToDevice, p.h2d));
+  HIP_TRY(c, hipMemcpyAsync(p.img[slot] + N, right, N, hipMemcpyHostToDevice, p.h2d));
+  if (flow) HIP_TRY(c, hipMemcpyAsync(p.flow[slot], flow, 8 * N, hipMemcpyHostToDevice, p.h2d));
+  HIP_TRY(c, hipEventRecord(p.ev_in[slot], p.h2d));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, p.ev_in[slot], 0));
+  // estimateDisparity (:258-279) on the GPU, straight into the ring: this plane is `now` here and `previous` of the next frame.
+  // Kernels of older frames that read the plane being replaced are ahead of the estimator on the same stream.
+  if ((rc = mod_sgm_compute_dev(c, 1, p.img[slot], p.img[slot] + N, sgm, p.dnow[nowi]))) return rc;
+  HIP_TRY(c, hipEventRecord(p.ev_img[slot], c->stream));
+  HIP_TRY(c, hipEventRecord(p.ev_ring, c->stream));
+  p.img_used[slot] = true; p.ring_by_kernels = true;
+  const bool had_prev = p.have_prev;
+  p.dring++; p.have_prev = true;    // disparity_previous_ = disparity_now_, whatever construct() does with the frame (:397-398)
+  // the guards of construct() (:104,110,122,127,133), in its order; disparity_now exists by now
+  if (!flow) return MOD_SKIP_NO_FLOW;
+  if (!had_prev) return MOD_SKIP_NO_DISPARITY_PREV;
+  if (!transform) return MOD_SKIP_NO_TRANSFORM;
+  ModFrameBatch in{};
+  in.frames = 1; in.disparity_now = p.dnow[nowi]; in.disparity_prev = p.dnow[previ];
+  in.flow = p.flow[slot]; in.transforms = transform; in.dt = &dt;
+  ModSceneFlowPlanes pl;
+  memset(&pl, 0, sizeof(pl));
+  float *q = p.planes[slot];
+  pl.x = q; pl.y = q + N; pl.z = q + 2 * N; pl.vx = q + 3 * N; pl.vy = q + 4 * N; pl.vz = q + 5 * N;
+  pl.cloud_aos = cloud_aos ? p.aos[slot] : nullptr;
+  ModClusterOut out{};
+  out.labels = labels ? p.labels[slot] : nullptr; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
+  if ((rc = mod_process_dev(c, &in, &pl, &out))) return rc;
+  HIP_TRY(c, hipEventRecord(p.ev_done[slot], c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(p.d2h, p.ev_done[slot], 0));
+  HIP_TRY(c, hipMemcpyAsync(p.h_n[slot], p.nobj[slot], sizeof(int32_t), hipMemcpyDeviceToHost, p.d2h));
+  if (labels) HIP_TRY(c, hipMemcpyAsync(labels, p.labels[slot], sizeof(int32_t) * N, hipMemcpyDeviceToHost, p.d2h));
+  if (disparity) HIP_TRY(c, hipMemcpyAsync(disparity, p.dnow[nowi], sizeof(float) * N, hipMemcpyDeviceToHost, p.d2h));
+  const int32_t ncopy = objects ? std::max(0, std::min(max_objects, (int32_t)c->max_objects)) : 0;
+  if (ncopy > 0) HIP_TRY(c, hipMemcpyAsync(p.h_obj[slot], p.objects[slot], sizeof(ModObject) * ncopy, hipMemcpyDeviceToHost, p.d2h));
+  p.user_obj[slot] = objects; p.user_cap[slot] = ncopy;
+  if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, p.aos[slot], 32 * N, hipMemcpyDeviceToHost, p.d2h));
+  HIP_TRY(c, hipEventRecord(p.ev_out[slot], p.d2h));
+  *ticket = (int32_t)(p.seq & 0x7fffffff);
+  p.seq++; p.in_flight++;
   return MOD_OK;
 }
 

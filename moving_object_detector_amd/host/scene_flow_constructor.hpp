@@ -187,6 +187,40 @@ class SceneFlowConstructor {
     check(rc);
     return ticket;
   }
+  // Pipelined stereoCallback() with the estimator on the GPU (BASELINE config 5): estimateDisparity() + construct() of one frame
+  // in a single submission — images go in, the disparity plane is produced in HBM, serves as `now` here and as `previous` of the
+  // next frame (disparity_previous_ = disparity_now_, :397-398) and never crosses the host link (estimateDisparity() + submit()
+  // carry it to the host and back).  Returns a ticket for collect(), or -1 where nothing will be published; a missing or
+  // mis-sized image plays the part of a failed estimateDisparity() (:272-276).
+  int submitStereo(const mod_host::Image *left_image, const mod_host::Image *right_image, const mod_host::FlowImage *left_flow,
+                   const mod_host::Transform *transform_prev2now, mod_host::PointCloud2 *pc_with_velocity,
+                   mod_host::MovingObjectArray *moving_objects = nullptr) {
+    const bool images = left_image && right_image && left_image->data && right_image->data && left_image->width == image_width_ &&
+                        left_image->height == image_height_ && right_image->width == image_width_ && right_image->height == image_height_;
+    ModTransform tf{};
+    if (transform_prev2now) {
+      for (int i = 0; i < 3; i++) tf.t[i] = transform_prev2now->translation[i];
+      for (int i = 0; i < 4; i++) tf.q[i] = transform_prev2now->rotation[i];
+    }
+    const double dt = (images && have_stamp_) ? mod_host::duration_sec(left_image->header.stamp, previous_stamp_) : 0.0;
+    const size_t n = (size_t)image_width_ * image_height_;
+    if (images && pc_with_velocity && pc_with_velocity->data.size() != n * 32) pc_with_velocity->data.resize(n * 32);
+    Pending &p = pending_[next_slot_];
+    p.objects.resize(max_objects_);
+    int32_t ticket = -1;
+    const int rc = mod_submit_stereo_host(ctx_, images ? left_image->data : nullptr, images ? right_image->data : nullptr, &sgm_,
+                                          left_flow ? left_flow->data : nullptr, transform_prev2now ? &tf : nullptr, dt,
+                                          pc_with_velocity ? pc_with_velocity->data.data() : nullptr, nullptr, p.objects.data(),
+                                          (int32_t)p.objects.size(), nullptr, &ticket);
+    have_parked_ = false;                         // the previous disparity lives in HBM (or is gone with the images)
+    if (images) { previous_stamp_ = left_image->header.stamp; have_stamp_ = true; }
+    else have_stamp_ = false;
+    if (rc > 0) return -1;
+    check(rc);
+    p.ticket = ticket; p.cloud = pc_with_velocity; p.objs = moving_objects; p.header = left_flow->header;
+    next_slot_ = (next_slot_ + 1) % MOD_PIPELINE_DEPTH;
+    return ticket;
+  }
   void collect(int ticket) {
     for (Pending &p : pending_) {
       if (p.ticket != ticket) continue;

@@ -172,6 +172,34 @@ int main(int argc, char **argv) {
         disp.header.frame_id != "left_camera") { fprintf(stderr, "disparity message fields wrong\n"); return 22; }
     if (est.estimateDisparity(nullptr, &right, li, ri, &disp, &pixels)) { fprintf(stderr, "a missing image must fail\n"); return 23; }
     write_all(dir + "/sgm_disparity.f32", pixels.data(), pixels.size() * 4);
+    // submitStereo(): the same image pair twice (a camera that stands still), a flow that moves a region — the device-resident
+    // path must give the bytes of estimateDisparity() + construct() with the disparity carried through the host
+    {
+      std::vector<float> sflow((size_t)SW * SH * 2, 0.0f);
+      for (int y = SH / 4; y < SH / 2; y++) for (int x = SW / 4; x < SW / 2; x++) sflow[((size_t)y * SW + x) * 2] = -9.0f;
+      mod_host::FlowImage sfl;
+      sfl.width = SW; sfl.height = SH; sfl.data = sflow.data(); sfl.header.frame_id = "left_camera";
+      mod_host::Transform still;                      // identity
+      mod_host::Image left2 = left, right2 = right;
+      left2.header.stamp = right2.header.stamp = mod_host::Time(7, 66666672u);
+      sfl.header.stamp = left2.header.stamp;
+      mod_host::PointCloud2 ca, cb;
+      mod_host::MovingObjectArray oa, ob;
+      const int s0 = est.submitStereo(&left, &right, nullptr, nullptr, &ca, &oa);       // first frame: no flow, no previous disparity
+      const int s1 = est.submitStereo(&left2, &right2, &sfl, &still, &ca, &oa);
+      if (s0 != -1 || s1 < 0) { fprintf(stderr, "submitStereo ticket pattern wrong: %d %d\n", s0, s1); return 24; }
+      est.collect(s1);
+      mod_host::DisparityImage d0 = disp, d1 = disp;
+      d1.header.stamp = left2.header.stamp;
+      scene_flow_constructor::SceneFlowConstructor ref(sctx);
+      ref.setCameraInfo(li, first);
+      if (!ref.construct(&d1, &d0, &sfl, &still, &cb, nullptr, &ob)) { fprintf(stderr, "reference stereo frame not published\n"); return 25; }
+      if (ca.data != cb.data) { fprintf(stderr, "submitStereo cloud differs from estimateDisparity + construct\n"); return 26; }
+      if (oa.moving_object_array.size() != ob.moving_object_array.size()) { fprintf(stderr, "submitStereo object count differs\n"); return 27; }
+      const int s2 = est.submitStereo(nullptr, &right2, &sfl, &still, &ca, &oa);        // a missing image: nothing published ...
+      const int s3 = est.submitStereo(&left2, &right2, &sfl, &still, &ca, &oa);         // ... and the next frame has no previous disparity
+      if (s2 != -1 || s3 != -1) { fprintf(stderr, "submitStereo after a missing image: %d %d\n", s2, s3); return 28; }
+    }
     mod_destroy(sctx);
   }
   printf("ok %zu objects\n", objs_cluster.moving_object_array.size());

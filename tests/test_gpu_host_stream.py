@@ -112,3 +112,90 @@ def test_pinned_host_memory_helpers():
     C.memset(p.value, 0x5A, 1 << 20)
     assert ctx.lib.mod_host_free(ctx.h, p) == 0
     ctx.close()
+
+
+def test_stereo_stream_matches_estimate_then_process():
+    """mod_submit_stereo_host (images in, disparity resident in HBM as `now` and next frame's `previous`) against the two-call path
+    mod_sgm_compute_host + mod_process_frame_host, which carries the disparity through the host: same disparity, cloud, labels,
+    objects, byte for byte — on the committed 320 x 240 image pair and four more frames of the same scene; guards as construct()."""
+    import os
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sgm_320x240.npz"))
+    H, W = g["left"].shape
+    D, F, CAP = 128, 5, 32
+    N = W * H
+    lefts, rights, truths = [np.ascontiguousarray(g["left"])], [np.ascontiguousarray(g["right"])], [g["truth"]]
+    for k in range(1, F):
+        l, r, t = synth.make_stereo_images(W, H, 11, D)             # the fixture's scene again (seed 11): a camera that stands still
+        lefts.append(l); rights.append(r); truths.append(t)
+    assert np.array_equal(lefts[1], lefts[0])
+    cam = synth.make_camera(W, H)
+    cam.min_disparity, cam.max_disparity = np.float32(0.0), np.float32(D - 1)
+    prm = synth.Params(cluster_size=150)
+    flows = [synth.make_box_flow(truths[k], shift=12.0 + k) for k in range(F)]      # the boxes move, a little more every frame
+    tf = capi.transforms_array(np.zeros((F, 3)), np.tile(np.array([[0.0, 0.0, 0.0, 1.0]]), (F, 1)))
+    sp = capi.ModSgmParams(D, 6, 96, 8, 1, 1)
+    dt = 1.0 / 15.0
+
+    def two_calls():
+        ctx = Context(W, H, max_frames=1)
+        ctx.set_camera(cam); ctx.set_params(prm)
+        disp = np.zeros((F, H, W), np.float32)
+        clouds = np.zeros((F, N, 8), np.float32); labels = np.full((F, N), -7, np.int32)
+        objs = [(capi.ModObject * CAP)() for _ in range(F)]
+        counts, n = [], C.c_int32(-1)
+        for f in range(F):
+            assert ctx.lib.mod_sgm_compute_host(ctx.h, lefts[f].ctypes.data, rights[f].ctypes.data, C.byref(sp), disp[f].ctypes.data) == 0
+            if f == 0:
+                counts.append(None)                                   # no previous disparity: construct() publishes nothing
+                continue
+            rc = ctx.lib.mod_process_frame_host(ctx.h, disp[f].ctypes.data, disp[f - 1].ctypes.data, flows[f].ctypes.data, C.byref(tf[f]), dt,
+                                                clouds[f].ctypes.data, labels[f].ctypes.data, objs[f], CAP, C.byref(n))
+            assert rc == 0
+            counts.append(n.value)
+        ctx.close()
+        return disp, clouds, labels, objs, counts
+
+    def one_call():
+        ctx = Context(W, H, max_frames=1)
+        ctx.set_camera(cam); ctx.set_params(prm)
+        disp = np.zeros((F, H, W), np.float32)
+        clouds = np.zeros((F, N, 8), np.float32); labels = np.full((F, N), -7, np.int32)
+        objs = [(capi.ModObject * CAP)() for _ in range(F)]
+        counts, tickets, t, n = [], [], C.c_int32(-1), C.c_int32(-1)
+        sub = lambda f, fl, tfp, d=None: ctx.lib.mod_submit_stereo_host(
+            ctx.h, lefts[f].ctypes.data, rights[f].ctypes.data, C.byref(sp), fl, tfp, dt, clouds[f].ctypes.data, labels[f].ctypes.data, objs[f], CAP,
+            d, C.byref(t))
+        # frame 0: no previous disparity yet -> skip code, but its disparity stays as frame 1's previous one
+        assert sub(0, flows[0].ctypes.data, C.byref(tf[0])) == capi.MOD_SKIP_NO_DISPARITY_PREV and t.value == -1
+        counts.append(None)
+        for f in range(1, F):
+            if f == 3:                                                # a frame without flow in between: skipped, yet it is frame 4's previous
+                assert sub(f, None, C.byref(tf[f])) == capi.MOD_SKIP_NO_FLOW and t.value == -1
+                counts.append(None)
+                continue
+            assert sub(f, flows[f].ctypes.data, C.byref(tf[f]), disp[f].ctypes.data) == 0, ctx.lib.mod_last_error(ctx.h)
+            tickets.append(t.value)
+        for tk in tickets:
+            assert ctx.lib.mod_collect_frame_host(ctx.h, tk, C.byref(n)) == 0
+            counts.append(n.value)
+        # no images: the estimator has nothing, and the NEXT frame has no previous disparity
+        assert ctx.lib.mod_submit_stereo_host(ctx.h, None, rights[0].ctypes.data, C.byref(sp), flows[0].ctypes.data, C.byref(tf[0]), dt, None, None, None, 0,
+                                              None, C.byref(t)) == capi.MOD_SKIP_NO_DISPARITY_NOW
+        assert sub(1, flows[1].ctypes.data, C.byref(tf[1])) == capi.MOD_SKIP_NO_DISPARITY_PREV
+        ctx.close()
+        return disp, clouds, labels, objs, counts
+
+    d0, c0, l0, o0, n0 = two_calls()
+    d1, c1, l1, o1, n1 = one_call()
+    assert np.array_equal(d0[0], g["disparity"])                       # the fixture pins the estimator
+    got = [n for n in n1 if n is not None]
+    want = [n0[f] for f in (1, 2, 4)]
+    assert got == want and max(want) > 0, (got, want)
+    for f in (1, 2, 4):
+        assert np.array_equal(d1[f], d0[f]), f                          # optional host copy of the device-resident plane
+        assert np.array_equal(l1[f], l0[f]), f
+        assert np.array_equal(c1[f].view(np.uint32)[..., [0, 1, 2, 4, 5, 6]], c0[f].view(np.uint32)[..., [0, 1, 2, 4, 5, 6]]), f
+        k = n0[f]
+        assert np.array_equal(np.frombuffer(bytes(o1[f]), np.uint8)[: 112 * k], np.frombuffer(bytes(o0[f]), np.uint8)[: 112 * k]), f
