@@ -44,7 +44,10 @@ for (W, H, NF) in ((1920, 1080, 24), (1280, 720, 40)):
             else:
                 d = disp[i % (capi.MOD_PIPELINE_DEPTH + 1)]
                 assert ctx.lib.mod_sgm_compute_host(ctx.h, left[f].ctypes.data, right[f].ctypes.data, C.byref(sp), d.ctypes.data) == 0
-                rc = ctx.lib.mod_submit_frame_host(ctx.h, d.ctypes.data, None, flow[f].ctypes.data, C.byref(tfs[f]), dt, None, labels[s].ctypes.data, objs[s], CAP,
+                # frame 0 ends at a guard before anything is enqueued, so frame 1 brings its previous disparity along (what the host
+                # mirror's submit() does with its parked copy); from then on the previous plane is resident
+                dprev = disp[(i - 1) % (capi.MOD_PIPELINE_DEPTH + 1)].ctypes.data if i == 1 else None
+                rc = ctx.lib.mod_submit_frame_host(ctx.h, d.ctypes.data, dprev, flow[f].ctypes.data, C.byref(tfs[f]), dt, None, labels[s].ctypes.data, objs[s], CAP,
                                                    C.byref(t))
             if rc == 0:
                 tickets.append(t.value)
