@@ -162,6 +162,13 @@ int  mod_scene_flow_dev(ModContext *ctx, const ModFrameBatch *in, const ModScene
 int  mod_depth_image_dev(ModContext *ctx, int32_t frames, const float *disparity_now, float *depth);
 int  mod_depth_image_host(ModContext *ctx, const float *disparity_now, float *depth);
 
+/* ~synthetic_optical_flow alone: calculateStaticOpticalFlow (scene_flow_constructor.cpp:65-89) — the flow a static scene would
+ * show under the camera motion `transform`: previous cloud reprojected, moved, projected (32FC2, NaN where the previous point is
+ * invalid).  construct() publishes it only for subscribers (:141-145); the batch entry points give it through
+ * ModSceneFlowPlanes.static_flow, this one for a node that holds host buffers.  One frame, synchronous.
+ * NULL disparity_prev -> MOD_SKIP_NO_DISPARITY_PREV, NULL transform -> MOD_SKIP_NO_TRANSFORM. */
+int  mod_static_flow_host(ModContext *ctx, const float *disparity_prev, const ModTransform *transform, float *static_flow);
+
 /* calculateDynamicMap (clusterer_nodelet.cpp:40-54) for a cloud that did not come from mod_scene_flow_dev. */
 int  mod_dynamic_mask_dev(ModContext *ctx, int32_t frames, const float *vx, const float *vy, const float *vz,
                           uint64_t *dynamic_mask);
@@ -219,7 +226,9 @@ int  mod_process_frame_host(ModContext *ctx,
                             ModObject *objects, int32_t max_objects, int32_t *n_objects);
 
 /* Clusterer alone on a host PointCloud2 payload (ClustererNodelet::dataCB, clusterer_nodelet.cpp:221-242).
- * point_step/row_step as in sensor_msgs/PointCloud2; fields x,y,z,vx,vy,vz at offsets 0,4,8,16,20,24. */
+ * point_step/row_step as in sensor_msgs/PointCloud2; fields x,y,z,vx,vy,vz at offsets 0,4,8,16,20,24.
+ * A context without a camera (a clusterer-only process: the nodelet) takes the image size from this call — the clusterer needs
+ * nothing else of the camera; parameters must have been set.  With a camera set, a cloud of another size is an error. */
 int  mod_cluster_cloud_host(ModContext *ctx, const void *cloud, int32_t width, int32_t height,
                             int32_t point_step, int32_t row_step,
                             int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects);

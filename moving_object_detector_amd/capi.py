@@ -38,7 +38,7 @@ EXPORTS = [
     "mod_cluster_dev", "mod_process_dev", "mod_pack_cloud_dev", "mod_unpack_cloud_dev", "mod_process_frame_host",
     "mod_cluster_cloud_host", "mod_submit_frame_host", "mod_submit_stereo_host", "mod_collect_frame_host", "mod_forget_previous", "mod_host_malloc", "mod_host_free",
     "mod_malloc", "mod_free", "mod_memcpy_h2d", "mod_memcpy_d2h", "mod_set_profiling",
-    "mod_get_stage_time", "mod_reset_stage_times", "mod_depth_image_dev", "mod_depth_image_host",
+    "mod_get_stage_time", "mod_reset_stage_times", "mod_depth_image_dev", "mod_depth_image_host", "mod_static_flow_host",
     "mod_sgm_census_dev", "mod_sgm_path_dev", "mod_sgm_compute_dev", "mod_sgm_compute_host",
 ]
 
@@ -128,6 +128,7 @@ def load(require_torch_first: bool = True):
     L.mod_scene_flow_dev.argtypes = [vp, C.POINTER(ModFrameBatch), C.POINTER(ModSceneFlowPlanes)]
     L.mod_depth_image_dev.argtypes = [vp, i32, vp, vp]
     L.mod_depth_image_host.argtypes = [vp, vp, vp]
+    L.mod_static_flow_host.argtypes = [vp, vp, C.POINTER(ModTransform), vp]
     L.mod_sgm_census_dev.argtypes = [vp, i32, vp, vp]
     L.mod_sgm_compute_dev.argtypes = [vp, i32, vp, vp, C.POINTER(ModSgmParams), vp]
     L.mod_sgm_compute_host.argtypes = [vp, vp, vp, C.POINTER(ModSgmParams), vp]

@@ -773,11 +773,49 @@ int mod_depth_image_host(ModContext *c, const float *disparity_now, float *depth
   return MOD_OK;
 }
 
-int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int32_t height, int32_t point_step,
-                           int32_t row_step, int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects) {
+int mod_static_flow_host(ModContext *c, const float *disparity_prev, const ModTransform *transform, float *static_flow) {
   int rc = check_ready(c, 1);
   if (rc) return rc;
+  if (!disparity_prev) return MOD_SKIP_NO_DISPARITY_PREV;
+  if (!transform) return MOD_SKIP_NO_TRANSFORM;
+  if (!static_flow) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null static-flow image");
+  if ((rc = ensure_host_staging(c))) return rc;
+  const size_t N = (size_t)c->dc.W * c->dc.H;
+  Buffers &b = c->b;
+  HIP_TRY(c, hipMemcpyAsync(b.h_dprev, disparity_prev, 4 * N, hipMemcpyHostToDevice, c->stream));
+  // the static flow depends on the previous disparity and the transform only (sceneflow.hip sf_stage1): the kernel's other
+  // inputs are fed the same plane / a zeroed flow, and its cloud goes to the staging planes nobody reads
+  HIP_TRY(c, hipMemsetAsync(b.h_flow, 0, 8 * N, c->stream));
+  ModFrameBatch in{};
+  const double dt = 1.0;
+  in.frames = 1; in.disparity_now = b.h_dprev; in.disparity_prev = b.h_dprev; in.flow = b.h_flow; in.transforms = transform; in.dt = &dt;
+  ModSceneFlowPlanes pl;
+  staged_planes(c, &pl);
+  pl.static_flow = reinterpret_cast<float *>(b.h_aos);      // 8 of the staging cloud's 32 bytes per pixel
+  if ((rc = mod_scene_flow_dev(c, &in, &pl))) return rc;
+  HIP_TRY(c, hipMemcpyAsync(static_flow, b.h_aos, 8 * N, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return MOD_OK;
+}
+
+int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int32_t height, int32_t point_step,
+                           int32_t row_step, int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects) {
+  if (!c) return MOD_ERR_INVALID_ARGUMENT;
+  int rc;
   if (n_objects) *n_objects = 0;
+  if (!c->has_cam) {
+    // A clusterer-only context (the nodelet lives in its own process, clusterer_nodelet.cpp:221-242): the clusterer reads the
+    // image size from the cloud it is handed and needs nothing else of the camera — the context takes the size from the call.
+    if (!c->has_prm) return fail(c, MOD_ERR_NOT_CONFIGURED, "parameters must be set first");
+    if (width < 1 || height < 1) return fail(c, MOD_ERR_INVALID_ARGUMENT, "cloud size must be positive");
+    if (width > c->cfg.max_width || height > c->cfg.max_height || (size_t)width * height > c->maxN)
+      return fail(c, MOD_ERR_CAPACITY, "cloud larger than ModConfig.max_width/max_height");
+    if (c->dc.W != width || c->dc.H != height) {
+      c->cam = ModCamera{};
+      c->cam.width = width; c->cam.height = height; c->cam.fx = c->cam.fy = 1.0;
+      refresh_devcam(c);
+    }
+  } else if ((rc = check_ready(c, 1))) return rc;
   if (!cloud) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null cloud");
   // an unorganized / mis-sized cloud is an error (the reference would throw from .at(), clusterer_nodelet.h:99-102)
   if (width != c->dc.W || height != c->dc.H) return fail(c, MOD_ERR_INVALID_ARGUMENT, "cloud size differs from the configured camera");
@@ -789,11 +827,11 @@ int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int3
                               hipMemcpyHostToDevice, c->stream));
   ModSceneFlowPlanes pl;
   staged_planes(c, &pl);
-  rc = mod_unpack_cloud_dev(c, 1, b.h_aos, &pl);
-  if (rc) return rc;
+  launch_unpack((size_t)width * height, b.h_aos, pl.x, pl.y, pl.z, pl.vx, pl.vy, pl.vz, c->stream);
+  HIP_TRY(c, hipGetLastError());
   ModClusterOut out{};
   out.labels = labels ? b.h_labels : nullptr; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
-  rc = mod_cluster_dev(c, 1, &pl, &out);
+  rc = run_cluster(c, 1, &pl, c->b.mask, false, false, &out);
   if (rc) return rc;
   return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
 }

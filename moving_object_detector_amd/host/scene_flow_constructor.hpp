@@ -12,10 +12,12 @@
 
 namespace scene_flow_constructor {
 
+#ifndef MOD_HOST_ROS_CONFIG   // a ROS build includes the dynamic_reconfigure-generated scene_flow_constructor/SceneFlowConstructorConfig.h first
 struct SceneFlowConstructorConfig {   // cfg/SceneFlowConstructor.cfg:8-9
   int dynamic_flow_diff = 5;
   double max_color_velocity = 1.0;    // unused by live code in the reference as well
 };
+#endif
 
 class SceneFlowConstructor {
  public:

@@ -64,6 +64,12 @@ def test_host_entry_points_match_golden(path):
         assert bits_equal(cloud[..., j], g[k]), k
     assert np.array_equal(labels, g["labels"]) and n.value == int(np.asarray(g["n_objects"]).item())
     compare_objects(objs[: n.value], golden_objects(g), strict_velocity=False)
+    # ~synthetic_optical_flow for a node with host buffers (calculateStaticOpticalFlow, scene_flow_constructor.cpp:65-89,141-145)
+    sflow = np.full((H, W, 2), 7.0, np.float32)
+    assert ctx.lib.mod_static_flow_host(ctx.h, g["d_prev"].ctypes.data, tf, sflow.ctypes.data) == 0
+    assert bits_equal(sflow, g["static_flow"])
+    assert ctx.lib.mod_static_flow_host(ctx.h, None, tf, sflow.ctypes.data) == capi.MOD_SKIP_NO_DISPARITY_PREV
+    assert ctx.lib.mod_static_flow_host(ctx.h, g["d_prev"].ctypes.data, None, sflow.ctypes.data) == capi.MOD_SKIP_NO_TRANSFORM
     # clusterer alone on the PointCloud2 payload (ClustererNodelet::dataCB)
     labels2 = np.zeros((H, W), np.int32)
     n2 = C.c_int32(-1)
@@ -76,6 +82,16 @@ def test_host_entry_points_match_golden(path):
     assert rc == 0 and n3.value == n.value and objs3[: n3.value].tobytes() == objs[: n.value].tobytes()
     rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W, H, 32, 32 * W, None, objs3.ctypes.data, 64, C.byref(n3))
     assert rc == 0 and n3.value == n.value and objs3[: n3.value].tobytes() == objs[: n.value].tobytes()
+    # a clusterer-only context (the nodelet in its own process): no camera is ever set, the size comes with the cloud
+    from moving_object_detector_amd.pipeline import Context
+    solo = Context(W + 7, H + 3, max_frames=1, max_objects=(W + 7) * (H + 3) // prm.cluster_size + 1)
+    assert solo.lib.mod_cluster_cloud_host(solo.h, cloud.ctypes.data, W, H, 32, 32 * W, labels2.ctypes.data, objs3.ctypes.data, 64, C.byref(n3)) == capi.MOD_ERR_NOT_CONFIGURED
+    solo.set_params(prm)
+    labels4 = np.full((H, W), -5, np.int32)
+    rc = solo.lib.mod_cluster_cloud_host(solo.h, cloud.ctypes.data, W, H, 32, 32 * W, labels4.ctypes.data, objs3.ctypes.data, 64, C.byref(n3))
+    assert rc == 0 and np.array_equal(labels4, g["labels"]) and n3.value == n.value and objs3[: n3.value].tobytes() == objs[: n.value].tobytes()
+    assert solo.lib.mod_cluster_cloud_host(solo.h, cloud.ctypes.data, W + 8, H, 32, 32 * W, None, objs3.ctypes.data, 64, C.byref(n3)) == capi.MOD_ERR_CAPACITY
+    solo.close()
     # a cloud of the wrong size is an error, not a silent skip
     rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W - 1, H, 32, 32 * W, labels2.ctypes.data, objs.ctypes.data, 64, C.byref(n2))
     assert rc == capi.MOD_ERR_INVALID_ARGUMENT and b"cloud size" in ctx.lib.mod_last_error(ctx.h)
