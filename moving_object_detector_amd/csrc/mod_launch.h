@@ -65,7 +65,11 @@ int ccl_request_capacity(int n);     // link requests one tile can emit at neigh
 
 // on-GPU disparity, first stages (sgm.hip)
 void launch_sgm_census(int W, int H, int frames, const uint8_t *img, uint32_t *out, hipStream_t s);
+// right_plane_padded: the 127 words before `cr` are readable (the four-lines-per-wave kernels of D == 128 read their census
+// windows unconditionally; words left of a row belong to disparities that do not exist and are never used)
 void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direction, const uint32_t *cl, const uint32_t *cr,
-                     uint8_t *L, uint8_t *cost, hipStream_t s);
+                     uint8_t *L, uint8_t *cost, bool right_plane_padded, hipStream_t s);
+bool launch_sgm_paths_all(int W, int H, int frames, int D, int P1, int P2, int paths, size_t path_stride, const uint32_t *cl, const uint32_t *cr,
+                          uint8_t *L, hipStream_t s);
 void launch_sgm_finish(int W, int H, int frames, int D, int paths, size_t path_stride, int median, int lr_check, const uint8_t *Lv,
                        uint8_t *dl, uint8_t *dr, uint8_t *dlm, uint8_t *drm, float *disparity, hipStream_t s);

@@ -576,9 +576,19 @@ int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left,
   if (!census_left || !census_right || !path_cost) return fail(c, MOD_ERR_INVALID_ARGUMENT, "null plane");
   if ((rc = check_sgm_params(c, p))) return rc;
   if (direction < 0 || direction > 7) return fail(c, MOD_ERR_INVALID_ARGUMENT, "direction must be 0..7");
-  launch_sgm_path(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction, census_left, census_right, path_cost,
-                  matching_cost, c->stream);
-  HIP_TRY(c, hipGetLastError());
+  // (stage entry point, tests and tracing) the D == 128 kernels read up to 127 words before the right plane: give them a padded copy
+  const size_t words = (size_t)frames * c->dc.W * c->dc.H;
+  uint32_t *padded = nullptr;
+  if (p->disparities == 128) {
+    HIP_TRY(c, hipMalloc((void **)&padded, (words + 128) * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(padded, 0, 128 * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(padded + 128, census_right, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+  }
+  launch_sgm_path(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction, census_left, padded ? padded + 128 : census_right, path_cost,
+                  matching_cost, padded != nullptr, c->stream);
+  const hipError_t le = hipGetLastError();
+  if (padded) { (void)hipStreamSynchronize(c->stream); (void)hipFree(padded); }
+  HIP_TRY(c, le);
   return MOD_OK;
 }
 
@@ -586,7 +596,8 @@ int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left,
 // frames of a group run side by side): per frame two census planes, one uint8 cost volume PER PATH (written once, never read
 // back by the path kernels: a running sum would put its load latency into every step of a path), four disparity maps.  Census
 // planes and volumes exist twice: consecutive groups overlap (mod_sgm_compute_dev).
-constexpr int kSgmGroup = 8, kSgmPaths = 8;
+constexpr int kSgmPaths = 8;
+static const int kSgmGroup = [] { const char *e = getenv("MOD_SGM_GROUP"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();   // frames per group (experiment knob)
 constexpr size_t kSgmVolumeBudget = (size_t)24 << 30;    // bytes of cost volumes a context may hold
 
 static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
@@ -637,6 +648,7 @@ int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, cons
   const int ngroups = (frames + group - 1) / group;
   const size_t set_census = 2 * N * group, set_volumes = N * (size_t)D * group * kSgmPaths;
   uint8_t *dl = b.sgm_maps, *dr = dl + N * group, *dlm = dr + N * group, *drm = dlm + N * group;
+  bool all_in_one[2] = {false, false};
   auto start = [&](int k) -> int {
     const int f0 = k * group, g = std::min(group, frames - f0), s = k & 1;
     uint32_t *cl = b.sgm_census + s * set_census, *cr = cl + N * g;
@@ -644,10 +656,18 @@ int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, cons
     launch_sgm_census(W, H, g, right + (size_t)f0 * N, cr, c->stream);
     HIP_TRY(c, hipEventRecord(b.sgm_fork[s], c->stream));
     const size_t path_stride = N * (size_t)D * g;        // one volume [g][H][W][D] per path
+    // the published configuration: all paths in ONE grid on one side stream (sgm.hip k_sgm_paths_all)
+    HIP_TRY(c, hipStreamWaitEvent(b.sgm_side[0], b.sgm_fork[s], 0));
+    if (launch_sgm_paths_all(W, H, g, D, p->p1, p->p2, p->paths, path_stride, cl, cr, b.sgm_S + s * set_volumes, b.sgm_side[0])) {
+      HIP_TRY(c, hipEventRecord(b.sgm_join[s][0], b.sgm_side[0]));
+      all_in_one[s] = true;
+      return MOD_OK;
+    }
+    all_in_one[s] = false;
     for (int i = 0; i < p->paths; i++) {
       HIP_TRY(c, hipStreamWaitEvent(b.sgm_side[i], b.sgm_fork[s], 0));   // a failed wait would let a path read census planes in flight
       launch_sgm_path(W, H, g, D, p->p1, p->p2, p->paths == 4 ? order4[i] : i, cl, cr, b.sgm_S + s * set_volumes + (size_t)i * path_stride,
-                      nullptr, b.sgm_side[i]);
+                      nullptr, /*right_plane_padded=*/true, b.sgm_side[i]);   // cr follows cl inside the scratch allocation
       HIP_TRY(c, hipEventRecord(b.sgm_join[s][i], b.sgm_side[i]));
     }
     return MOD_OK;
@@ -655,7 +675,7 @@ int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, cons
   auto finish = [&](int k) -> int {
     const int f0 = k * group, g = std::min(group, frames - f0), s = k & 1;
     // a failed wait would let the winner-take-all read volumes the path kernels are still writing: surface it
-    for (int i = 0; i < p->paths; i++) HIP_TRY(c, hipStreamWaitEvent(c->stream, b.sgm_join[s][i], 0));
+    for (int i = 0; i < (all_in_one[s] ? 1 : p->paths); i++) HIP_TRY(c, hipStreamWaitEvent(c->stream, b.sgm_join[s][i], 0));
     launch_sgm_finish(W, H, g, D, p->paths, N * (size_t)D * g, p->median, p->lr_check, b.sgm_S + s * set_volumes, dl, dr, dlm, drm,
                       disparity + (size_t)f0 * N, c->stream);
     return MOD_OK;

@@ -131,10 +131,19 @@ __device__ __forceinline__ void sf_stage2a(const DevCam &c, const FrameConst &fc
   // cloud (!isValid); a NaN x passes through the transform untouched -> invalid
   const bool ok = st.go & disp_in_range(c, dpw) & !is_nan_inf_or_negative(dpw) & !(dpw == 0.0f) & !isnan(Xp);
   // ---- residual test (scene_flow_constructor.cpp:196-198): sqrtf(acc) >= flow_th  <=>  acc >= flow_th_sq (host-derived) ----
+#ifdef SF_PACKED_F32   // experiment build: the residual's two lanes as one packed pair (v_pk_add_f32 / v_pk_mul_f32); same roundings
+  typedef float sf_f2 __attribute__((ext_vector_type(2)));
+  const sf_f2 fl = {st.f0, st.f1}, sf = {o.s0, o.s1};
+  const sf_f2 rr = fl - sf, sq = rr * rr;
+  float acc = 0.0f;
+  acc = acc + sq.x;
+  acc = acc + sq.y;
+#else
   const float r0 = st.f0 - o.s0, r1 = st.f1 - o.s1;
   float acc = 0.0f;
   acc = acc + r0 * r0;
   acc = acc + r1 * r1;
+#endif
   const bool moving = acc >= c.flow_th_sq;
   const float safe = (float)fc.pad[0];
   const bool settled = ok & !moving & (fabsf(Xp) <= safe) & (fabsf(Yp) <= safe) & (fabsf(zp) <= safe);
@@ -259,9 +268,12 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     sf_stage1(c, fc, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2, s2);
     sf_stage1(c, fc, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3, s3);
     // x, y, z are final after stage 1: their stores leave before the gathers come back
+    // (SF_LATE_XYZ, an experiment build: all six plane stores in one clause at the end — profiles/README.md round 3)
+#ifndef SF_LATE_XYZ
     st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
     st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
     st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
+#endif
     // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets; so do the scalar
     // loads of the output pointers that are needed from here on
     float *const out_vx = LATE_A(vx), *const out_vy = LATE_A(vy), *const out_vz = LATE_A(vz);
@@ -294,6 +306,11 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
       sf_stage2b(c, fc, s2, w2, p2);
       sf_stage2b(c, fc, s3, w3, p3);
     }
+#ifdef SF_LATE_XYZ
+    st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
+    st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
+    st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
+#endif
     st(out_vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
     st(out_vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
     st(out_vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
@@ -322,6 +339,102 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     }
   }
 }
+
+#ifdef SF_8PX
+// Experiment build (profiles/README.md round 3): 8 pixels per thread — two groups of 4 consecutive pixels 256 pixels apart, so that
+// every wave-level load / store stays one contiguous kilobyte; FrameConst, the row's ray, the address setup and the epilogue are
+// paid once per 8 pixels.  Same stage functions, same results.
+__global__ __launch_bounds__(256) void k_scene_flow_v8(DevCam c, SfArgs a) {
+  const int lane = threadIdx.x;
+  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+    if ((total & 7u) == 0u) {
+      const uint32_t lin = bx + gridDim.x * (by + gridDim.y * bz);
+      const uint32_t m = (lin & 7u) * (total >> 3) + (lin >> 3);
+      bx = m % gridDim.x;
+      const uint32_t t = m / gridDim.x;
+      by = t % gridDim.y; bz = t / gridDim.y;
+    }
+  }
+  const int y = by * 4 + threadIdx.y;
+  const int f = bz;
+  const size_t fN = (size_t)f * ((size_t)c.W * c.H);
+  const FrameConst fc = a.fc[f];
+  const float *dprev_f = a.dprev + fN;
+  const uint32_t W = (uint32_t)c.W;
+  int x0[2];
+  bool inb[2];
+  uint32_t o4[2], nib[2] = {0u, 0u};
+  float4 dn[2], dp[2], fa[2], fb[2];
+  double2 rxa[2], rxb[2];
+  const double ry = c.rayy[min(y, c.H - 1)];
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    x0[g] = (bx * 128 + g * 64 + lane) * 4;
+    inb[g] = (x0[g] < c.W) && (y < c.H);
+    const uint32_t pix = (uint32_t)min(y, c.H - 1) * W + (uint32_t)min(x0[g], c.W - 4);
+    o4[g] = pix * 4u;
+    dn[g] = ld<float4>(a.dnow + fN, o4[g]);
+    dp[g] = ld<float4>(dprev_f, o4[g]);
+    fa[g] = ld<float4>(a.flow + 2 * fN, pix * 8u);
+    fb[g] = ld<float4>(a.flow + 2 * fN, pix * 8u + 16u);
+    rxa[g] = ld<double2>(c.rayx, (uint32_t)min(x0[g], c.W - 4) * 8u);
+    rxb[g] = ld<double2>(c.rayx, (uint32_t)min(x0[g], c.W - 4) * 8u + 16u);
+  }
+#pragma unroll
+  for (int g = 0; g < 2; g++) {
+    Px p0, p1, p2, p3;
+    PxState s0, s1, s2, s3;
+    const int xg = min(x0[g], c.W - 4);
+    sf_stage1(c, fc, xg + 0, y, dn[g].x, dp[g].x, fa[g].x, fa[g].y, rxa[g].x, ry, p0, s0);
+    sf_stage1(c, fc, xg + 1, y, dn[g].y, dp[g].y, fa[g].z, fa[g].w, rxa[g].y, ry, p1, s1);
+    sf_stage1(c, fc, xg + 2, y, dn[g].z, dp[g].z, fb[g].x, fb[g].y, rxb[g].x, ry, p2, s2);
+    sf_stage1(c, fc, xg + 3, y, dn[g].w, dp[g].w, fb[g].z, fb[g].w, rxb[g].y, ry, p3, s3);
+    if (inb[g]) {
+      st(a.x + fN, o4[g], make_float4(p0.x, p1.x, p2.x, p3.x));
+      st(a.y + fN, o4[g], make_float4(p0.y, p1.y, p2.y, p3.y));
+      st(a.z + fN, o4[g], make_float4(p0.z, p1.z, p2.z, p3.z));
+    }
+    const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
+    const float g1 = ld<float>(dprev_f, ((uint32_t)s1.py * W + (uint32_t)s1.px) * 4u);
+    const float g2 = ld<float>(dprev_f, ((uint32_t)s2.py * W + (uint32_t)s2.px) * 4u);
+    const float g3 = ld<float>(dprev_f, ((uint32_t)s3.py * W + (uint32_t)s3.px) * 4u);
+    const double ax0 = ld<double>(c.rayx, (uint32_t)s0.px * 8u), ax1 = ld<double>(c.rayx, (uint32_t)s1.px * 8u);
+    const double ax2 = ld<double>(c.rayx, (uint32_t)s2.px * 8u), ax3 = ld<double>(c.rayx, (uint32_t)s3.px * 8u);
+    const double ay0 = ld<double>(c.rayy, (uint32_t)s0.py * 8u), ay1 = ld<double>(c.rayy, (uint32_t)s1.py * 8u);
+    const double ay2 = ld<double>(c.rayy, (uint32_t)s2.py * 8u), ay3 = ld<double>(c.rayy, (uint32_t)s3.py * 8u);
+    PxWarp w0, w1, w2, w3;
+    sf_stage2a(c, fc, s0, g0, ax0, ay0, p0, w0);
+    sf_stage2a(c, fc, s1, g1, ax1, ay1, p1, w1);
+    sf_stage2a(c, fc, s2, g2, ax2, ay2, p2, w2);
+    sf_stage2a(c, fc, s3, g3, ax3, ay3, p3, w3);
+    if (__any(w0.todo | w1.todo | w2.todo | w3.todo)) {
+      sf_stage2b(c, fc, s0, w0, p0);
+      sf_stage2b(c, fc, s1, w1, p1);
+      sf_stage2b(c, fc, s2, w2, p2);
+      sf_stage2b(c, fc, s3, w3, p3);
+    }
+    if (inb[g]) {
+      st(a.vx + fN, o4[g], make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
+      st(a.vy + fN, o4[g], make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
+      st(a.vz + fN, o4[g], make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
+      nib[g] = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u) | (p2.dyn ? 4u : 0u) | (p3.dyn ? 8u : 0u);
+    }
+  }
+  if (a.mask) {
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+      const uint64_t w = nibbles_to_word(nib[g], lane);
+      const int word = (bx * 128 + g * 64 + lane) / 16;
+      if ((lane & 15) == 0 && y < c.H && word < c.mask_words) {
+        a.mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
+        if (a.tilehdr && w) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + word) * 2] = 1;
+      }
+    }
+  }
+}
+#endif
 
 // Even widths that are not a multiple of 4 (the reference's own working resolution is 1242 x 376, detect_with_zed.launch:10):
 // rows are 8-byte aligned, so thread = 2 consecutive pixels (float2 loads / stores, one float4 of flow), wave = 128 px.
@@ -465,6 +578,13 @@ __global__ __launch_bounds__(256) void k_unpack(size_t n, const float4 *aos, flo
 void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s) {
   dim3 block(64, 4, 1);
   if ((c.W & 3) == 0) {
+#ifdef SF_8PX
+    if (!a.aos && !a.depth && !a.sflow && c.W >= 4) {   // the experiment kernel writes the six planes and the mask only
+      dim3 grid8((c.W / 4 + 127) / 128, (c.H + 3) / 4, frames);
+      hipLaunchKernelGGL(k_scene_flow_v8, grid8, block, 0, s, c, a);
+      return;
+    }
+#endif
     dim3 grid((c.W / 4 + 63) / 64, (c.H + 3) / 4, frames);
     hipLaunchKernelGGL(k_scene_flow_v4, grid, block, 0, s, c, a);
   } else if ((c.W & 1) == 0) {

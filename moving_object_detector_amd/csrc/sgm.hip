@@ -8,6 +8,8 @@
 // Kernels: census transform, the eight aggregation paths (matching cost computed on the fly, never stored unless asked),
 // winner-take-all over the summed paths (left and right disparity), 3 x 3 median, left-right check.
 #include "mod_launch.h"
+#include <cstdlib>
+#include <string>
 
 namespace {
 
@@ -234,6 +236,166 @@ __global__ __launch_bounds__(64) void k_sgm_path_line(int W, int H, int D, int P
   }
 }
 
+// FOUR path lines per wave (D == 128): lane = (line q of the wave's four, slot t of 16), slot t owns the EIGHT disparities
+// 8t .. 8t + 7 as four packed pairs.  Against one line per wave (lane = two disparities, above):
+//   * the minimum over the 128 disparities is 3 packed minima inside the lane + 4 DPP steps inside the 16-lane row (quad swaps, half
+//     mirror, mirror) and stays in a vector register — no row_bcast steps, no v_readlane, no scalar round trip per step;
+//   * six of the eight d - 1 / d + 1 neighbours are register moves (v_alignbit between the lane's own pairs); only the pair ends
+//     cross a lane (one row_shr:1 and one row_shl:1 per step);
+//   * one 8-byte store per lane and step; the lane's eight right census words are eight CONSECUTIVE words (two 16-byte loads).
+// ~70 vector instructions per step of four lines (17 per line step, one-line kernels: ~30) and a shorter dependent chain.
+// The four lines of a wave are neighbours (rows / columns / diagonals next to each other); they may differ in length by a few
+// pixels: a line that has ended keeps computing on its last pixel and stores nothing.
+typedef uint32_t sgm_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t sgm_u2 __attribute__((ext_vector_type(2)));
+// UNIFORM: the wave's four lines exist and have one length (rows / columns of an image whose height / width is a multiple of 4):
+// every step stores unconditionally, so the compiler can count the memory operations in flight and the wait in front of a census
+// slot leaves the younger slot's loads outstanding (a conditional store makes it wait for everything).  COST: also emit the
+// matching cost (stage entry point only).
+template <int RX, int RY, bool UNIFORM, bool COST>
+__device__ __forceinline__ void sgm_path_q_body(int W, int H, int P1, int P2, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
+                                                SgmOut out, int blk, int f) {
+  constexpr int D = 128, kPF = 2;
+  const int lane = threadIdx.x, q = lane >> 4, t = lane & 15;
+  const int nlines = RY == 0 ? H : (RX == 0 ? W : W + H - 1);
+  const int line = blk * 4 + q;
+  int x = 0, y = 0, len = 0;
+  if (line < nlines) {
+    if (RY == 0) { y = line; x = RX > 0 ? 0 : W - 1; len = W; }
+    else {
+      if (line < W) { x = RX < 0 ? W - 1 - line : line; y = RY > 0 ? 0 : H - 1; }
+      else { x = RX > 0 ? 0 : W - 1; y = RY > 0 ? line - W + 1 : H - 2 - (line - W); }
+      len = RY > 0 ? H - y : y + 1;
+      if (RX > 0) len = min(len, W - x);
+      if (RX < 0) len = min(len, x + 1);
+    }
+  }
+  const int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                         max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+  const size_t plane = (size_t)f * H * W, vol = plane * D;
+  SGM_GLOBAL uint8_t *cl_b = sgm_uniform(cl + plane), *cr_b = sgm_uniform(cr + plane);
+  SGM_GLOBAL uint8_t *outL = sgm_uniform(out.L + vol), *outC = COST ? sgm_uniform(out.C + vol) : nullptr;
+  const uint32_t p1pk = (uint32_t)P1 | ((uint32_t)P1 << 16), p2pk = (uint32_t)P2 | ((uint32_t)P2 << 16);
+  const int dbase = 8 * t;
+  // census words of the line's k-th pixel (clamped to the line): the left word, and the eight right words x - dbase - 7 .. x - dbase
+  // (word j of the window belongs to disparity dbase + 7 - j).  Where a window would start left of the row (x < 127 somewhere in the
+  // wave) every word is fetched on its own at max(x - d, 0): such disparities do not exist and get the border cost below.
+  struct Slot { uint32_t wl; uint32_t r[8]; };
+  auto fetch = [&](int k, Slot &sl) {
+    const int kk = max(min(k, len - 1), 0), xx = x + RX * kk, yy = y + RY * kk;
+    const uint32_t rowo = (uint32_t)(yy * W) * 4u;
+    sl.wl = *(const SGM_GLOBAL uint32_t *)(cl_b + (rowo + (uint32_t)xx * 4u));
+    // ALWAYS the same three loads (the compiler can then count them: the wait before a slot's use leaves the younger slot's loads
+    // in flight).  Near the left border the window starts left of the row — in the row above, or (first row of the plane) up to
+    // 127 words before the plane: the caller guarantees those bytes are readable; the words read there belong to disparities
+    // that do not exist and are replaced by the border cost.
+    const SGM_GLOBAL sgm_u4 *w = (const SGM_GLOBAL sgm_u4 *)(cr_b + (int32_t)(rowo + (uint32_t)(xx - dbase - 7) * 4u));
+    const sgm_u4 a = w[0], b = w[1];
+    sl.r[0] = a.x; sl.r[1] = a.y; sl.r[2] = a.z; sl.r[3] = a.w; sl.r[4] = b.x; sl.r[5] = b.y; sl.r[6] = b.z; sl.r[7] = b.w;
+  };
+  Slot slot[kPF];
+#pragma unroll
+  for (int u = 0; u < kPF; u++) fetch(u, slot[u]);
+  uint32_t lp[4] = {0, 0, 0, 0};
+  uint32_t shp = kSgmNone << 16, shn = kSgmNone;       // DPP shift registers: the row's end lanes keep "no such disparity"
+  for (int i0 = 0; i0 < maxlen; i0 += kPF) {            // wave-uniform
+#pragma unroll
+    for (int u = 0; u < kPF; u++) {
+      const int i = i0 + u;
+      if (i >= maxlen) break;                           // wave-uniform
+      const int kk = max(min(i, len - 1), 0), xx = x + RX * kk, yy = y + RY * kk;
+      // matching costs of the lane's eight disparities (31 where the disparity leaves the right image)
+      uint32_t c[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        c[j] = (uint32_t)__popc(slot[u].wl ^ slot[u].r[7 - 2 * j]) + ((uint32_t)__popc(slot[u].wl ^ slot[u].r[6 - 2 * j]) << 16);
+      if (!__all(xx >= D - 1)) {                        // wave-uniform: only near the left border
+        const int nvalid = xx - dbase + 1;              // disparities dbase .. dbase + nvalid - 1 exist (d <= x)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t lo = 2 * j < nvalid ? (c[j] & 0xffffu) : 31u, hi = 2 * j + 1 < nvalid ? (c[j] >> 16) : 31u;
+          c[j] = lo | (hi << 16);
+        }
+      }
+      fetch(i + kPF, slot[u]);                          // the slot is free again
+      uint32_t l[4];
+      if (i > 0) {
+        // minimum over the line's 128 path costs: inside the lane, then a butterfly over the row's 16 lanes
+        uint32_t m = pk_min(pk_min(lp[0], lp[1]), pk_min(lp[2], lp[3]));
+        m = min(m & 0xffffu, m >> 16);
+        asm("s_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+            "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+            : "+v"(m));
+        const uint32_t mpk = m | (m << 16), mp2pk = pk_add(mpk, p2pk);
+        shp = (uint32_t)__builtin_amdgcn_update_dpp((int)shp, (int)lp[3], 0x111, 0xF, 0xF, false);   // row_shr:1: the slot below's last pair
+        shn = (uint32_t)__builtin_amdgcn_update_dpp((int)shn, (int)lp[0], 0x101, 0xF, 0xF, false);   // row_shl:1: the slot above's first pair
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t below = j == 0 ? shp : lp[j - 1], above = j == 3 ? shn : lp[j + 1];
+          const uint32_t a = __builtin_amdgcn_alignbit(lp[j], below, 16), b = __builtin_amdgcn_alignbit(above, lp[j], 16);   // d - 1, d + 1
+          const uint32_t best = pk_min(pk_min(lp[j], mp2pk), pk_add(pk_min(a, b), p1pk));
+          l[j] = pk_sub(pk_add(c[j], best), mpk);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) l[j] = c[j];
+      }
+      if (UNIFORM || i < len) {                         // lines that have ended store nothing
+        const uint32_t at = (uint32_t)(yy * W + xx) * (uint32_t)D + (uint32_t)dbase;
+        sgm_u2 v;
+        v.x = __builtin_amdgcn_perm(l[1], l[0], 0x06040200u); v.y = __builtin_amdgcn_perm(l[3], l[2], 0x06040200u);
+        *(SGM_GLOBAL sgm_u2 *)(outL + at) = v;
+        if (COST) {
+          v.x = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u); v.y = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u);
+          *(SGM_GLOBAL sgm_u2 *)(outC + at) = v;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) lp[j] = l[j];
+    }
+  }
+}
+
+template <int RX, int RY, bool UNIFORM, bool COST>
+__global__ __launch_bounds__(64) void k_sgm_path_q(int W, int H, int P1, int P2, const uint32_t *__restrict__ cl,
+                                                   const uint32_t *__restrict__ cr, SgmOut out) {
+  sgm_path_q_body<RX, RY, UNIFORM, COST>(W, H, P1, P2, cl, cr, out, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// All aggregation paths of a group of frames in ONE launch: blockIdx.x runs over the four-line blocks of direction 0, then 1, ...
+// (the rows first: they are the longest lines, 1280 steps at 720p).  One grid instead of eight kernels on eight streams: the HIP
+// runtime maps streams onto 4 hardware queues by default, so only four of the eight path kernels ever ran side by side (kernel
+// trace of round 3) and the short ones queued behind the long ones; inside one grid the dispatcher fills every free wave slot
+// with whatever block is next.  Path i writes its volume at out.L + i * path_stride.
+template <bool UH, bool UV>
+__global__ __launch_bounds__(64) void k_sgm_paths_all(int W, int H, int P1, int P2, int paths, size_t path_stride, const uint32_t *__restrict__ cl,
+                                                      const uint32_t *__restrict__ cr, uint8_t *__restrict__ L) {
+  const int nh = (H + 3) / 4, nv = (W + 3) / 4, nd = (W + H - 1 + 3) / 4;
+  int blk = (int)blockIdx.x;
+  const int f = (int)blockIdx.y;
+  SgmOut o{L, nullptr};
+  // numbering of oracle/sgm_ref.cpp: 0 (+1,0) 1 (-1,0) 2 (0,+1) 3 (0,-1) 4 (+1,+1) 5 (-1,-1) 6 (-1,+1) 7 (+1,-1)
+  if (blk < nh) { sgm_path_q_body<1, 0, UH, false>(W, H, P1, P2, cl, cr, o, blk, f); return; }
+  blk -= nh; o.L += path_stride;
+  if (blk < nh) { sgm_path_q_body<-1, 0, UH, false>(W, H, P1, P2, cl, cr, o, blk, f); return; }
+  blk -= nh; o.L += path_stride;
+  if (blk < nv) { sgm_path_q_body<0, 1, UV, false>(W, H, P1, P2, cl, cr, o, blk, f); return; }
+  blk -= nv; o.L += path_stride;
+  if (blk < nv) { sgm_path_q_body<0, -1, UV, false>(W, H, P1, P2, cl, cr, o, blk, f); return; }
+  if (paths <= 4) return;
+  blk -= nv; o.L += path_stride;
+  if (blk < nd) { sgm_path_q_body<1, 1, false, false>(W, H, P1, P2, cl, cr, o, blk, f); return; }
+  blk -= nd; o.L += path_stride;
+  if (blk < nd) { sgm_path_q_body<-1, -1, false, false>(W, H, P1, P2, cl, cr, o, blk, f); return; }
+  blk -= nd; o.L += path_stride;
+  if (blk < nd) { sgm_path_q_body<-1, 1, false, false>(W, H, P1, P2, cl, cr, o, blk, f); return; }
+  blk -= nd; o.L += path_stride;
+  sgm_path_q_body<1, -1, false, false>(W, H, P1, P2, cl, cr, o, blk, f);
+}
+
 // Winner-take-all over the sum of the path volumes, one workgroup (4 waves) per image row.  A wave takes every fourth pixel:
 // lane l owns disparities 2l and 2l + 1 (one 2-byte load per path volume), sums the paths, and
 //   left  disparity of x : first minimum of S(x, .)              -> DPP minimum over keys (S << 8 | d): the smallest d wins ties
@@ -356,7 +518,7 @@ void launch_sgm_census(int W, int H, int frames, const uint8_t *img, uint32_t *o
 }
 
 void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direction, const uint32_t *cl, const uint32_t *cr,
-                     uint8_t *L, uint8_t *cost, hipStream_t s) {
+                     uint8_t *L, uint8_t *cost, bool right_plane_padded, hipStream_t s) {
   SgmOut o{L, cost};
   const size_t lds = ((size_t)2 * W + 1) * sizeof(uint32_t);
   const dim3 b(64);
@@ -372,8 +534,49 @@ void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direct
     case 6: hipLaunchKernelGGL((k_sgm_path_line<-1, 1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                     \
     default: hipLaunchKernelGGL((k_sgm_path_line<1, -1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                    \
   }
+  // D == 128 (the published configuration): four lines per wave; MOD_SGM_PATH=line keeps the one-line kernels for A/B runs
+  static const bool one_line = [] { const char *e = std::getenv("MOD_SGM_PATH"); return e && std::string(e) == "line"; }();
+  if (D == 128 && !one_line && right_plane_padded) {
+    const dim3 qh((H + 3) / 4, frames), qv((W + 3) / 4, frames), qd((W + H - 1 + 3) / 4, frames);
+    const bool uh = (H & 3) == 0, uv = (W & 3) == 0;
+#define SGM_Q(RX, RY, UNI, GRID)                                                                                            \
+    do {                                                                                                                    \
+      if (cost) { if (UNI) hipLaunchKernelGGL((k_sgm_path_q<RX, RY, true, true>), GRID, b, 0, s, W, H, P1, P2, cl, cr, o);   \
+                  else hipLaunchKernelGGL((k_sgm_path_q<RX, RY, false, true>), GRID, b, 0, s, W, H, P1, P2, cl, cr, o); }     \
+      else { if (UNI) hipLaunchKernelGGL((k_sgm_path_q<RX, RY, true, false>), GRID, b, 0, s, W, H, P1, P2, cl, cr, o);        \
+             else hipLaunchKernelGGL((k_sgm_path_q<RX, RY, false, false>), GRID, b, 0, s, W, H, P1, P2, cl, cr, o); }         \
+    } while (0)
+    switch (direction) {
+      case 0: SGM_Q(1, 0, uh, qh); break;
+      case 1: SGM_Q(-1, 0, uh, qh); break;
+      case 2: SGM_Q(0, 1, uv, qv); break;
+      case 3: SGM_Q(0, -1, uv, qv); break;
+      case 4: SGM_Q(1, 1, false, qd); break;
+      case 5: SGM_Q(-1, -1, false, qd); break;
+      case 6: SGM_Q(-1, 1, false, qd); break;
+      default: SGM_Q(1, -1, false, qd); break;
+    }
+#undef SGM_Q
+    return;
+  }
   if (D == 128) { SGM_PATH(true) } else { SGM_PATH(false) }
 #undef SGM_PATH
+}
+
+// every path of the published configuration (D == 128) in one grid; returns false when the combination is not covered (other D,
+// MOD_SGM_PATH=line): the caller then launches the paths one by one
+bool launch_sgm_paths_all(int W, int H, int frames, int D, int P1, int P2, int paths, size_t path_stride, const uint32_t *cl, const uint32_t *cr,
+                          uint8_t *L, hipStream_t s) {
+  static const bool one_line = [] { const char *e = std::getenv("MOD_SGM_PATH"); return e && (std::string(e) == "line" || std::string(e) == "streams"); }();
+  if (D != 128 || one_line || (paths != 8 && paths != 4)) return false;
+  const int nh = (H + 3) / 4, nv = (W + 3) / 4, nd = (W + H - 1 + 3) / 4;
+  const dim3 g(2 * nh + 2 * nv + (paths == 8 ? 4 * nd : 0), frames), b(64);
+  const bool uh = (H & 3) == 0, uv = (W & 3) == 0;
+  if (uh && uv) hipLaunchKernelGGL((k_sgm_paths_all<true, true>), g, b, 0, s, W, H, P1, P2, paths, path_stride, cl, cr, L);
+  else if (uh) hipLaunchKernelGGL((k_sgm_paths_all<true, false>), g, b, 0, s, W, H, P1, P2, paths, path_stride, cl, cr, L);
+  else if (uv) hipLaunchKernelGGL((k_sgm_paths_all<false, true>), g, b, 0, s, W, H, P1, P2, paths, path_stride, cl, cr, L);
+  else hipLaunchKernelGGL((k_sgm_paths_all<false, false>), g, b, 0, s, W, H, P1, P2, paths, path_stride, cl, cr, L);
+  return true;
 }
 
 void launch_sgm_finish(int W, int H, int frames, int D, int paths, size_t path_stride, int median, int lr_check, const uint8_t *Lv,
