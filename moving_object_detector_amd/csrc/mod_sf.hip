@@ -612,7 +612,23 @@ static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
       HIP_TRY(c, hipEventCreateWithFlags(&b.sgm_fork[k], hipEventDisableTiming));
       for (int i = 0; i < 8; i++) HIP_TRY(c, hipEventCreateWithFlags(&b.sgm_join[k][i], hipEventDisableTiming));
     }
-    for (int i = 0; i < 8; i++) HIP_TRY(c, hipStreamCreateWithFlags(&b.sgm_side[i], hipStreamNonBlocking));
+    // The path grid occupies every wave slot of the CUs it may use for milliseconds (a row's wave walks 1280 steps); the
+    // winner-take-all of the group before it, an HBM-bound kernel on the context's stream, would only get slots as path waves
+    // retire.  The path stream therefore leaves one CU in every `keep` free (MOD_SGM_CU_KEEP, default 8; 0 = no mask).
+    {
+      static const int keep = [] { const char *e = getenv("MOD_SGM_CU_KEEP"); const int v = e ? atoi(e) : 8; return v >= 0 && v <= 64 ? v : 8; }();
+      hipDeviceProp_t prop;
+      HIP_TRY(c, hipGetDeviceProperties(&prop, c->cfg.device));
+      const int ncu = prop.multiProcessorCount;
+      if (keep >= 2 && ncu >= 2 * keep) {
+        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+        for (int i = 0; i < ncu; i++) if (i % keep != keep - 1) mask[i / 32] |= 1u << (i % 32);
+        HIP_TRY(c, hipExtStreamCreateWithCUMask(&b.sgm_side[0], (uint32_t)mask.size(), mask.data()));
+      } else {
+        HIP_TRY(c, hipStreamCreateWithFlags(&b.sgm_side[0], hipStreamNonBlocking));
+      }
+    }
+    for (int i = 1; i < 8; i++) HIP_TRY(c, hipStreamCreateWithFlags(&b.sgm_side[i], hipStreamNonBlocking));
   }
   if (b.sgm_S && b.sgm_D >= D && b.sgm_G >= g) return MOD_OK;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -246,6 +246,9 @@ __global__ __launch_bounds__(64) void k_sgm_path_line(int W, int H, int D, int P
 // ~70 vector instructions per step of four lines (17 per line step, one-line kernels: ~30) and a shorter dependent chain.
 // The four lines of a wave are neighbours (rows / columns / diagonals next to each other); they may differ in length by a few
 // pixels: a line that has ended keeps computing on its last pixel and stores nothing.
+#ifndef SGM_QPF
+#define SGM_QPF 2   // census slots in flight per line (steps of prefetch)
+#endif
 typedef uint32_t sgm_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t sgm_u2 __attribute__((ext_vector_type(2)));
 // UNIFORM: the wave's four lines exist and have one length (rows / columns of an image whose height / width is a multiple of 4):
@@ -255,7 +258,7 @@ typedef uint32_t sgm_u2 __attribute__((ext_vector_type(2)));
 template <int RX, int RY, bool UNIFORM, bool COST>
 __device__ __forceinline__ void sgm_path_q_body(int W, int H, int P1, int P2, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
                                                 SgmOut out, int blk, int f) {
-  constexpr int D = 128, kPF = 2;
+  constexpr int D = 128, kPF = SGM_QPF;
   const int lane = threadIdx.x, q = lane >> 4, t = lane & 15;
   const int nlines = RY == 0 ? H : (RX == 0 ? W : W + H - 1);
   const int line = blk * 4 + q;
@@ -344,9 +347,16 @@ __device__ __forceinline__ void sgm_path_q_body(int W, int H, int P1, int P2, co
         for (int j = 0; j < 4; j++) l[j] = c[j];
       }
       if (UNIFORM || i < len) {                         // lines that have ended store nothing
+#if defined(SGM_EXP) && SGM_EXP == 2   // timing experiment: every store lands in the first megabyte (cache-resident), results are wrong
+        const uint32_t at = ((uint32_t)(yy * W + xx) * (uint32_t)D + (uint32_t)dbase) & 0xFFFFFu;
+#else
         const uint32_t at = (uint32_t)(yy * W + xx) * (uint32_t)D + (uint32_t)dbase;
+#endif
         sgm_u2 v;
         v.x = __builtin_amdgcn_perm(l[1], l[0], 0x06040200u); v.y = __builtin_amdgcn_perm(l[3], l[2], 0x06040200u);
+#if defined(SGM_EXP) && SGM_EXP == 1   // timing experiment: no store at all (kept alive by an impossible condition), results are wrong
+        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
+#endif
         *(SGM_GLOBAL sgm_u2 *)(outL + at) = v;
         if (COST) {
           v.x = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u); v.y = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u);
