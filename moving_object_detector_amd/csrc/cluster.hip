@@ -671,7 +671,8 @@ __device__ __forceinline__ uint32_t seg_run_min(uint32_t v, uint64_t L) {
 
 template <bool N4>
 __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
-  __shared__ float Z[PH * PW];            // depth of the grid: row r = image row y0 - 4 + r, column j = image column x0 - 4 + j
+  // (the depth of the grid is NOT kept in LDS: the window pass reads the few depths it needs from global memory — cache hits, the
+  // tile's rows were loaded a moment ago — so that a wave holds 2.8 KB of LDS instead of 8.2 and eight waves fit a SIMD)
   __shared__ uint16_t LAB[PH * PW];       // labels: cell id (r * PW + j) of the smallest cell of the set, | kHaloBit for halo cells
   const int lane = threadIdx.x;
   const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
@@ -714,15 +715,13 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
     mH = (uint32_t)(qL >> 60) & (0xFu << (HL - n)) & 0xFu;          // only the n nearest columns can be window cells
   }
   const uint32_t mMlo = (uint32_t)q0, mMhi = (uint32_t)(q0 >> 32);   // dynamic bits of the 64 tile columns
-  float zr[PH], zh[PH];
+  float zr[PH];
   {
-    const int xc = min(x0 + lane, c.W - 1), xh = max(x0 - HL + min(lane, HL - 1), 0);
+    const int xc = min(x0 + lane, c.W - 1);
 #pragma unroll
     for (int r = 0; r < PH; r++) {
       const int gy = min(max(y0 - HL + r, 0), c.H - 1);
-      const size_t rowp = fN + (size_t)gy * c.W;
-      zr[r] = a.z[rowp + xc];
-      zh[r] = a.z[rowp + xh];
+      zr[r] = a.z[fN + (size_t)gy * c.W + xc];
     }
   }
   // ---- setup: grid into LDS; link masks of the two pre-linked positions (left, up); labels = first cell of the pixel's run ----
@@ -734,9 +733,7 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
       const uint64_t Mr = rd64(mMlo, mMhi, r);
       const uint32_t Hr = rd32(mH, r);
       const float zc = zr[r];
-      Z[r * PW + HL + lane] = zc;
       if (lane < HL) {
-        Z[r * PW + lane] = zh[r];
         LAB[r * PW + lane] = (uint16_t)(((Hr >> lane) & 1u) ? (uint32_t)(kHaloBit | (r * PW + lane)) : kNoLabel);
       }
       uint32_t lab = kNoLabel;
@@ -757,6 +754,11 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
   }
   asm volatile("" ::: "memory");           // one wave: its LDS operations execute in order; only the compiler must not reorder them
   RSTAMP(12)
+  // depth of grid cell (row r, column j) from global memory; cells outside the image are never dynamic, their value is not used
+  auto zcell = [&](int r, int j) -> float {
+    const int gy = min(max(y0 - HL + r, 0), c.H - 1), gx = min(max(x0 - HL + j, 0), c.W - 1);
+    return a.z[fN + (size_t)gy * c.W + gx];
+  };
   // ---- sweeps: row r takes the labels straight above (below) its vertically linked pixels, then its runs are levelled ----
   auto sweep = [&](const bool down, const bool force) -> bool {
     bool changed = false;
@@ -828,13 +830,13 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
           if ((__ballot(lq[dv][k] != cur) & C) | (C & ~U)) need |= 1u << (dv * 5 + k);
         }
       if (need == 0) continue;
-      const float zp = Z[r * PW + HL + lane];
+      const float zp = zcell(r, HL + lane);
       float zq[5][5];
 #pragma unroll
       for (int dv = 0; dv <= 4; dv++)
 #pragma unroll
         for (int k = 0; k <= 4; k++)
-          if ((dv | k) != 0 && (N4 || (dv <= n && k <= n))) zq[dv][k] = Z[(r - dv) * PW + HL + lane - k];
+          if ((dv | k) != 0 && (N4 || (dv <= n && k <= n))) zq[dv][k] = zcell(r - dv, HL + lane - k);
 #pragma unroll
       for (int dv = 0; dv <= 4; dv++)
 #pragma unroll
@@ -978,9 +980,9 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
       if (i < PH * HL && ((hr >> j) & 1u)) {
         lab = LAB[r * PW + j];
         if (!(lab & kHaloBit)) {
-          const float zme = Z[r * PW + j];
-          const bool cov_up = r > 0 && ((hu >> j) & 1u) && LAB[(r - 1) * PW + j] == lab && !(fabsf(zme - Z[(r - 1) * PW + j]) > th);
-          const bool cov_left = j > 0 && ((hr >> (j - 1)) & 1u) && LAB[r * PW + j - 1] == lab && !(fabsf(zme - Z[r * PW + j - 1]) > th);
+          const float zme = zcell(r, j);
+          const bool cov_up = r > 0 && ((hu >> j) & 1u) && LAB[(r - 1) * PW + j] == lab && !(fabsf(zme - zcell(r - 1, j)) > th);
+          const bool cov_left = j > 0 && ((hr >> (j - 1)) & 1u) && LAB[r * PW + j - 1] == lab && !(fabsf(zme - zcell(r, j - 1)) > th);
           want = !(cov_up || cov_left);
         }
       }
@@ -1166,6 +1168,11 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
 // x = F32(ray_x(column) * (double)z), y = F32(ray_y(row) * (double)z) (sceneflow.hip sf_stage1, getPoint3D): the members' x, y are
 // then recomputed from z and the ray tables — the same two operations, the same bits — instead of being read back (8 B/px of the
 // active tiles less for this HBM-bound kernel).  Caller-supplied clouds (mod_cluster_dev) are read as they are.
+#ifndef FINAL_PLAIN_LABELS   // streaming stores for the label plane: nobody on the GPU reads it (k_final 1.03 -> 0.97 ms per 512 pairs)
+#define FINAL_ST(p, v) __builtin_nontemporal_store((int)(v), (p))
+#else
+#define FINAL_ST(p, v) (*(p) = (v))
+#endif
 template <int TH, int NW, bool XY_FROM_Z>
 __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   constexpr int RPW = TH / NW;
@@ -1179,7 +1186,7 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   if (a.tilehdr[tidx * 2] == 0) {                    // nothing dynamic in the tile
     if (a.labels) {
 #pragma unroll
-      for (int j = 0; j < RPW; j++) { const int y = y0 + r0 + j; if (y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = -1; }
+      for (int j = 0; j < RPW; j++) { const int y = y0 + r0 + j; if (y < c.H && x < c.W) FINAL_ST(&a.labels[fN + (size_t)y * c.W + x], -1); }
     }
     return;
   }
@@ -1224,7 +1231,7 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
     int l = dyn ? nlmap[cl] : -1;
     if (!MOD_CHECK(a, l >= -1 && l < a.max_objects, 7)) l = -1;
     nl[j] = l; cell[j] = cl; rank[j] = 0;
-    if (a.labels && y < c.H && x < c.W) a.labels[fN + (size_t)y * c.W + x] = l;
+    if (a.labels && y < c.H && x < c.W) FINAL_ST(&a.labels[fN + (size_t)y * c.W + x], l);
     any_member = any_member || (__ballot(l >= 0) != 0);
   }
   // ---- members: counted per tile root in LDS ----
