@@ -48,7 +48,7 @@ def test_packaging():
             assert t in cm, t
         doc = xml.dom.minidom.parse(os.path.join(ADAPTER, pkg, "package.xml"))
         assert doc.getElementsByTagName("name")[0].firstChild.data == pkg
-        deps = {d.firstChild.data for d in doc.getElementsByTagName("depend")}
+        deps = {d.firstChild.data for tag in ("depend", "build_depend", "exec_depend") for d in doc.getElementsByTagName(tag)}
         src = "".join(open(os.path.join(ADAPTER, pkg, "src", f)).read() for f in os.listdir(os.path.join(ADAPTER, pkg, "src")))
         for header_pkg in ("dynamic_reconfigure", "sensor_msgs", "roscpp"):
             assert header_pkg in deps, (pkg, header_pkg)
