@@ -669,16 +669,22 @@ __device__ __forceinline__ uint32_t seg_run_min(uint32_t v, uint64_t L) {
   return v;
 }
 
+#ifndef ROWS_TPW
+#define ROWS_TPW 1     // tiles (= waves) per workgroup; the waves of a workgroup share nothing
+#endif
 template <bool N4>
-__global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
+__global__ __launch_bounds__(64 * ROWS_TPW) void k_ccl_rows(DevCam c, ClArgs a) {
   // (the depth of the grid is NOT kept in LDS: the window pass reads the few depths it needs from global memory — cache hits, the
   // tile's rows were loaded a moment ago — so that a wave holds 2.8 KB of LDS instead of 8.2 and eight waves fit a SIMD)
-  __shared__ uint16_t LAB[PH * PW];       // labels: cell id (r * PW + j) of the smallest cell of the set, | kHaloBit for halo cells
-  const int lane = threadIdx.x;
-  const int wi = blockIdx.x, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
+  __shared__ uint16_t LABs[ROWS_TPW][PH * PW];   // labels: cell id (r * PW + j) of the smallest cell of the set, | kHaloBit for halo cells
+  const int lane = threadIdx.x, wv_ = ROWS_TPW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.y) : 0;
+  uint16_t *const LAB = LABs[wv_];
+  const int tiles_x = c.mask_words;
+  const int wi = blockIdx.x * ROWS_TPW + wv_, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
+  if (ROWS_TPW > 1 && wi >= tiles_x) return;
   const int MW = c.mask_words, n = N4 ? 4 : c.n;        // n <= 4; the default 4 has its own instance (constant window bounds)
   const size_t N = (size_t)c.W * c.H, fN = (size_t)f * N;
-  int *hdr = a.tilehdr + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * 2;
+  int *hdr = a.tilehdr + ((size_t)f * gridDim.y * tiles_x + (size_t)blockIdx.y * tiles_x + wi) * 2;
   if (__builtin_amdgcn_readfirstlane(hdr[0]) == 0) return;          // no dynamic pixel in the tile: one scalar load
   const float th = c.depth_th;
 #ifdef MOD_PHASE_COUNTERS   // diagnostic build only (make PHASE_COUNTERS=1, tools/dbg_rows_counters.py): event counts and cycles per tile
@@ -947,7 +953,7 @@ __global__ __launch_bounds__(64) void k_ccl_rows(DevCam c, ClArgs a) {
   // whose root is not known yet -> (halo pixel, tile root) for k_ccl_link; a cell whose left / upper neighbour is a halo cell of
   // the same set with a direct link leaves it to that neighbour (that link is one the tile owning the cell sees itself) ----
   int nreq = 0;
-  uint2 *req = a.requests + ((size_t)f * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + wi) * a.req_cap;
+  uint2 *req = a.requests + ((size_t)f * gridDim.y * tiles_x + (size_t)blockIdx.y * tiles_x + wi) * a.req_cap;
   auto emit = [&](bool want, int hg, uint32_t lab) {
     const uint64_t wb = __ballot(want);
     if (wb == 0) return;
@@ -1888,8 +1894,9 @@ void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
   // MOD_TILE_KERNEL=rows selects the one-wave-per-tile kernel (k_ccl_rows, neighbor_distance <= 4): bit-exact, a third of the
   // instructions, and SLOWER (4.6 vs 2.2 ms per 512 pairs, profiles/r03_tile_kernel_notes.md) — kept as the measured alternative
   static const bool use_rows = [] { const char *e = std::getenv("MOD_TILE_KERNEL"); return e && std::string(e) == "rows"; }();
-  if (c.n == 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<true>, tgrid, dim3(64, 1, 1), 0, s, c, a); return; }
-  if (c.n < 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<false>, tgrid, dim3(64, 1, 1), 0, s, c, a); return; }
+  const dim3 rgrid((tgrid.x + ROWS_TPW - 1) / ROWS_TPW, tgrid.y, tgrid.z);
+  if (c.n == 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<true>, rgrid, dim3(64, ROWS_TPW, 1), 0, s, c, a); return; }
+  if (c.n < 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<false>, rgrid, dim3(64, ROWS_TPW, 1), 0, s, c, a); return; }
   if (c.n == 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, true>), tgrid, block, 0, s, c, a);
   else if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, false>), tgrid, block, 0, s, c, a);
   else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves, false>), tgrid, block, 0, s, c, a);
