@@ -182,8 +182,9 @@ def config5_leg(dev, local_rank):
         if key == "720":
             n = W * H
             gbs = 2 * PATHS * D * n / (sgm_frame_ms * 1e-3) / 1e9
-            # a path step is ~30 VALU instructions per wave, 4 cycles each, over 1024 SIMDs at 2.4 GHz
-            valu_ms = PATHS * n * 30 * 4 / (1024 * 2.4e9) * 1e3
+            # a step of four path lines is 84 VALU instructions per wave (927 M per dispatch of 11 M wave-steps, profiles/README.md
+            # round 3) = 21 per line step, 4 cycles each, over 1024 SIMDs at 2.4 GHz
+            valu_ms = PATHS * n * 21 * 4 / (1024 * 2.4e9) * 1e3
             out["sgm_ms_per_frame"] = sgm_frame_ms
             out["sgm_roofline"] = {"bytes_per_px": 2 * PATHS * D, "GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "valu_bound_ms": valu_ms,
                                    "frac_of_valu_bound": valu_ms / sgm_frame_ms, "at": "1280x720, 8 frames per group"}
