@@ -199,3 +199,48 @@ def test_stereo_stream_matches_estimate_then_process():
         assert np.array_equal(c1[f].view(np.uint32)[..., [0, 1, 2, 4, 5, 6]], c0[f].view(np.uint32)[..., [0, 1, 2, 4, 5, 6]]), f
         k = n0[f]
         assert np.array_equal(np.frombuffer(bytes(o1[f]), np.uint8)[: 112 * k], np.frombuffer(bytes(o0[f]), np.uint8)[: 112 * k]), f
+
+
+def test_stereo_and_disparity_submissions_share_the_ring():
+    """The two streaming entries may alternate on one context: a frame submitted as IMAGES leaves its disparity in the pipe's ring, and a
+    following frame submitted as a DISPARITY (mod_submit_frame_host with disparity_prev = NULL) pairs with it — also when the image
+    frame ended at a guard and took no ticket (the host copy then queues behind the estimator that is still writing the plane)."""
+    import os
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sgm_320x240.npz"))
+    H, W = g["left"].shape
+    D, N, CAP = 128, H * W, 32
+    left, right = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
+    cam = synth.make_camera(W, H)
+    cam.min_disparity, cam.max_disparity = np.float32(0.0), np.float32(D - 1)
+    prm = synth.Params(cluster_size=150)
+    sp = capi.ModSgmParams(D, 6, 96, 8, 1, 1)
+    flow = synth.make_box_flow(g["truth"], shift=14.0)
+    tf = capi.transforms_array(np.zeros((1, 3)), np.array([[0.0, 0.0, 0.0, 1.0]]))
+    dt = 1.0 / 15.0
+    disp = np.ascontiguousarray(g["disparity"])                        # the estimator's result for this pair (pinned by the fixture)
+
+    ctx = Context(W, H, max_frames=1)
+    ctx.set_camera(cam); ctx.set_params(prm)
+    t, n = C.c_int32(-1), C.c_int32(-1)
+    # frame 0 as images, no flow: ends at a guard, no ticket — but its disparity is now the resident previous plane
+    rc = ctx.lib.mod_submit_stereo_host(ctx.h, left.ctypes.data, right.ctypes.data, C.byref(sp), None, C.byref(tf[0]), dt, None, None, None, 0, None, C.byref(t))
+    assert rc == capi.MOD_SKIP_NO_FLOW and t.value == -1
+    # frame 1 as a disparity image, previous = the plane the estimator left behind
+    cloud1 = np.zeros((N, 8), np.float32); lab1 = np.full(N, -7, np.int32); objs1 = (capi.ModObject * CAP)()
+    rc = ctx.lib.mod_submit_frame_host(ctx.h, disp.ctypes.data, None, flow.ctypes.data, C.byref(tf[0]), dt, cloud1.ctypes.data, lab1.ctypes.data, objs1, CAP, C.byref(t))
+    assert rc == 0, ctx.lib.mod_last_error(ctx.h)
+    assert ctx.lib.mod_collect_frame_host(ctx.h, t.value, C.byref(n)) == 0
+    n1 = n.value
+    ctx.close()
+
+    ref = Context(W, H, max_frames=1)
+    ref.set_camera(cam); ref.set_params(prm)
+    cloud0 = np.zeros((N, 8), np.float32); lab0 = np.full(N, -7, np.int32); objs0 = (capi.ModObject * CAP)()
+    rc = ref.lib.mod_process_frame_host(ref.h, disp.ctypes.data, disp.ctypes.data, flow.ctypes.data, C.byref(tf[0]), dt, cloud0.ctypes.data, lab0.ctypes.data, objs0, CAP, C.byref(n))
+    assert rc == 0 and n.value == n1 and n1 > 0
+    ref.close()
+    assert np.array_equal(lab1, lab0)
+    assert np.array_equal(cloud1.view(np.uint32)[:, [0, 1, 2, 4, 5, 6]], cloud0.view(np.uint32)[:, [0, 1, 2, 4, 5, 6]])
+    assert bytes(objs1)[: 112 * n1] == bytes(objs0)[: 112 * n1]
