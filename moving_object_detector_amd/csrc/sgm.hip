@@ -384,8 +384,11 @@ __global__ __launch_bounds__(64) void k_sgm_path_q(int W, int H, int P1, int P2,
 // runtime maps streams onto 4 hardware queues by default, so only four of the eight path kernels ever ran side by side (kernel
 // trace of round 3) and the short ones queued behind the long ones; inside one grid the dispatcher fills every free wave slot
 // with whatever block is next.  Path i writes its volume at out.L + i * path_stride.
+#ifndef SGM_ALL_ATTR
+#define SGM_ALL_ATTR
+#endif
 template <bool UH, bool UV>
-__global__ __launch_bounds__(64) void k_sgm_paths_all(int W, int H, int P1, int P2, int paths, size_t path_stride, const uint32_t *__restrict__ cl,
+__global__ __launch_bounds__(64) SGM_ALL_ATTR void k_sgm_paths_all(int W, int H, int P1, int P2, int paths, size_t path_stride, const uint32_t *__restrict__ cl,
                                                       const uint32_t *__restrict__ cr, uint8_t *__restrict__ L) {
   const int nh = (H + 3) / 4, nv = (W + 3) / 4, nd = (W + H - 1 + 3) / 4;
   int blk = (int)blockIdx.x;
