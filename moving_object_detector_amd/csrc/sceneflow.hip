@@ -209,6 +209,21 @@ template <class T> __device__ __forceinline__ void st(void *base, uint32_t byte_
 // arithmetic: with them the kernel wants more than the 102 SGPRs a wave has and spills into VGPR lanes (v_writelane / v_readlane
 // pairs, which take VALU issue slots of a VALU-co-limited kernel).  Read through the kernarg segment pointer: taking the address of
 // a by-value parameter would make the compiler copy it to scratch.
+// Plane stores: SF_NT_PLANES is a bit mask (1 x, 2 y, 4 z, 8 vx, 16 vy, 32 vz) of the planes written with streaming (non-temporal)
+// stores — an experiment knob: means of six alternating runs on one box were 3.649 ms (0), 3.642 (x, y), 3.611 (all six), inside
+// the +-4 % a process varies by (profiles/README.md round 3).  Default 0: plain stores.
+#ifndef SF_NT_PLANES
+#define SF_NT_PLANES 0
+#endif
+template <int BIT> __device__ __forceinline__ void st_plane(float *base, uint32_t byte_off, float a0, float a1, float a2, float a3) {
+  if (SF_NT_PLANES & BIT) {
+    typedef float sf_w4 __attribute__((ext_vector_type(4)));
+    const sf_w4 v = {a0, a1, a2, a3};
+    __builtin_nontemporal_store(v, (sf_w4 *)((char *)base + byte_off));
+  } else {
+    st(base, byte_off, make_float4(a0, a1, a2, a3));
+  }
+}
 #define SF_K4 __attribute__((address_space(4)))
 template <class T> __device__ __forceinline__ T karg(size_t off) {
   const SF_K4 char *kp = (const SF_K4 char *)__builtin_amdgcn_kernarg_segment_ptr();
@@ -256,8 +271,15 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     const float *dprev_f = a.dprev + fN;
     const float4 dn = ld<float4>(a.dnow + fN, o4);
     const float4 dp = ld<float4>(dprev_f, o4);
+#ifdef SF_NT_FLOW   // experiment: the flow field is read exactly once
+    typedef float sf_v4 __attribute__((ext_vector_type(4)));
+    const sf_v4 fa_ = __builtin_nontemporal_load((const sf_v4 *)((const char *)(a.flow + 2 * fN) + o8));
+    const sf_v4 fb_ = __builtin_nontemporal_load((const sf_v4 *)((const char *)(a.flow + 2 * fN) + o8 + 16u));
+    const float4 fa = make_float4(fa_.x, fa_.y, fa_.z, fa_.w), fb = make_float4(fb_.x, fb_.y, fb_.z, fb_.w);
+#else
     const float4 fa = ld<float4>(a.flow + 2 * fN, o8);
     const float4 fb = ld<float4>(a.flow + 2 * fN, o8 + 16u);
+#endif
     const double ry = c.rayy[y];
     const double2 rxa = ld<double2>(c.rayx, (uint32_t)x0 * 8u);
     const double2 rxb = ld<double2>(c.rayx, (uint32_t)x0 * 8u + 16u);
@@ -270,9 +292,9 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     // x, y, z are final after stage 1: their stores leave before the gathers come back
     // (SF_LATE_XYZ, an experiment build: all six plane stores in one clause at the end — profiles/README.md round 3)
 #ifndef SF_LATE_XYZ
-    st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
-    st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
-    st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
+    st_plane<1>(a.x + fN, o4, p0.x, p1.x, p2.x, p3.x);
+    st_plane<2>(a.y + fN, o4, p0.y, p1.y, p2.y, p3.y);
+    st_plane<4>(a.z + fN, o4, p0.z, p1.z, p2.z, p3.z);
 #endif
     // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets; so do the scalar
     // loads of the output pointers that are needed from here on
@@ -307,13 +329,13 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
       sf_stage2b(c, fc, s3, w3, p3);
     }
 #ifdef SF_LATE_XYZ
-    st(a.x + fN, o4, make_float4(p0.x, p1.x, p2.x, p3.x));
-    st(a.y + fN, o4, make_float4(p0.y, p1.y, p2.y, p3.y));
-    st(a.z + fN, o4, make_float4(p0.z, p1.z, p2.z, p3.z));
+    st_plane<1>(a.x + fN, o4, p0.x, p1.x, p2.x, p3.x);
+    st_plane<2>(a.y + fN, o4, p0.y, p1.y, p2.y, p3.y);
+    st_plane<4>(a.z + fN, o4, p0.z, p1.z, p2.z, p3.z);
 #endif
-    st(out_vx + fN, o4, make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
-    st(out_vy + fN, o4, make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
-    st(out_vz + fN, o4, make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
+    st_plane<8>(out_vx + fN, o4, p0.vx, p1.vx, p2.vx, p3.vx);
+    st_plane<16>(out_vy + fN, o4, p0.vy, p1.vy, p2.vy, p3.vy);
+    st_plane<32>(out_vz + fN, o4, p0.vz, p1.vz, p2.vz, p3.vz);
     if (out_aos) {   // pcl::PointXYZVelocity records, 32 B each (pads written as 0)
       float4 *q = out_aos + 2 * fN;
       const uint32_t o32 = pix * 32u;
