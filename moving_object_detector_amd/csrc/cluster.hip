@@ -611,424 +611,282 @@ __device__ __forceinline__ void ccl_tile_body(const DevCam &c, const ClArgs &a, 
   if (tid == 0) hdr[1] = s_nreq;                   // s_nreq is final: the barrier after the request loop has passed (hdr[0] is 1 already)
 }
 
+// The same tile body for the tiles of a LIST (k_ccl_bits leaves the tiles it cannot decide there): a fixed number of workgroups,
+// each pulling the next tile with one atomic — the list is a fifth of the active tiles, one workgroup per grid tile would spend
+// the launch on 460 k header reads.  counters[4] = length of the list, counters[3] = cursor (both zeroed by the caller).
+template <int TH, int NMAX, int NW, bool EXACT>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ccl_tile_list(DevCam c, ClArgs a, int tiles_x, int tiles_y) {
+  __shared__ int s_next;
+  const int count = a.counters[4];
+  for (;;) {
+    if (threadIdx.x == 0 && threadIdx.y == 0) s_next = atomicAdd(&a.counters[3], 1);
+    __syncthreads();
+    const int i = __builtin_amdgcn_readfirstlane(s_next);
+    if (i >= count) return;
+    const uint32_t t = a.tilelist[i];
+    const int per_frame = tiles_x * tiles_y;
+    const int f = (int)(t / (uint32_t)per_frame), r = (int)(t - (uint32_t)f * (uint32_t)per_frame), ty = r / tiles_x, wi = r - ty * tiles_x;
+    ccl_tile_body<TH, NMAX, NW, EXACT>(c, a, wi, ty, f, tiles_x, tiles_y);
+    __syncthreads();                                 // the next tile re-uses the LDS arrays and s_next
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// k_ccl_rows — the tile stage for neighbor_distance <= 4 (the reference's default is 4, Clusterer.cfg:11): the same contract as
-// k_ccl_tile (parent[p] = tile root for every dynamic pixel of the tile, root bits, one (size, first_edge_key) record per tile
-// root, one link request per connected group of halo cells that a tile component reaches), a different decomposition.
+// k_ccl_bits — the tile stage on BIT PLANES, for the tiles whose depth gate cannot fire (neighbor_distance = 4, the reference's
+// default, Clusterer.cfg:11).
 //
-// k_ccl_tile's duration is its instruction issue time (profiles/r02_pmc_notes.md): a per-pixel union-find in LDS, four waves
-// and nine barriers per tile, ~17 000 wave-instructions per active tile, most of them issued for a handful of lanes.  Here
-//   * ONE wave owns a tile: lane = column, a grid row (tile row or one of the 4 halo rows above) is one register; no barrier,
-//     no atomic, no pointer chasing.  LDS holds the grid (depth and 16-bit labels, pitch 68 = 4 left-halo columns + 64) only so
-//     that a row can be fetched by a loop index and read shifted by k columns (the window's x - k) without lane shuffles;
-//   * a LINK MASK per window position is one v_sub + one v_cmp writing a 64-bit scalar mask, combined with the dynamic bits of the
-//     two rows on the scalar unit: E = M[r] & (M[r - dv] << k) & gate.  "Has an up-left edge" (first_edge_key) is the OR of those;
-//   * labels are the smallest cell id of the component: runs start with their first cell's id (closed form from the mask),
-//     a DOWN sweep (row r takes the minimum of the labels straight above its vertically linked pixels, then every run is
-//     levelled with a segmented min-scan over DPP row shifts / row_bcast, predicated by scalar masks derived from the run bits)
-//     and an UP sweep repeat until a sweep changes nothing: a convex blob needs one of each;
-//   * the remaining 22 window positions only VERIFY in the common case (labels already equal, every pixel has its edge): a row
-//     whose window rows all carry its one label and whose pixels all have an up-left edge costs a few scalar instructions;
-//     a link between different labels lowers both ends and sends the tile through the sweeps again (rare);
-//   * halo cells are nodes like any other (ids carry bit 15, so a component's smallest id is a tile pixel when it has one):
-//     the rows above take part in the sweeps, the 4 columns to the left live in LDS only and are reached by the window pass.
-// Semantics as clusterer_nodelet.cpp:56-83,186-219 (window = up-left quadrant, depth gate `!(|dz| > th)`, NaN links).
-namespace rows {
-constexpr int TH = 16, HL = 4, PH = TH + HL, PW = 64 + HL;
-constexpr uint32_t kNoLabel = 0xFFFFu;
+// comparePoints links two dynamic pixels unless |z_p - z_q| > depth_diff (clusterer_nodelet.cpp:186-219).  When the dynamic cells
+// of a tile and its halo span no more than depth_diff in depth — a tile inside or at the rim of one object: four fifths of the
+// active tiles of the synthetic street scene — no gate of the tile can fire, and its components are those of the MASK under the
+// up-left 5 x 5 window.  They are found without touching a pixel: ONE wave per tile, lane = grid row (4 halo rows above + 16 tile
+// rows), a row = 68 bits (4 halo columns + 64) in three registers, so that
+//   * "has an up-left edge" (first_edge_key), "is somebody's up-left neighbour" and the closing of <= 3-cell gaps are a few
+//     shifts / ORs per row, the rows above / below arrive by DPP wave shifts;
+//   * the usual tile (every row one closed run, every row linked to a row above) is ONE component by inspection;
+//   * anything else is flooded component by component from its first pixel in raster order (which is its root): per sweep the set
+//     grows by the window in all rows at once and fills the closed runs it touches with a carry chain (c + s ripples through a
+//     run of ones), 5-6 sweeps for a tile-high blob;
+//   * publishing turns a component's row bits into lane predicates (v_readlane -> exec): parent[p] = root, one (size,
+//     first_edge_key) record, root bits, one link request per connected group of halo cells — k_ccl_tile's contract.
+// ~700 wave-instructions per such tile against ~17 000 of the union-find kernel.  Tiles that fail the depth test go to a list for
+// k_ccl_tile_list.  Model of the bit algorithm against brute force: tests/models/ccl_bits_model.py.
+namespace bits {
+constexpr int TH = 16, HL = 4, PH = TH + HL;
 
-// value known to be the same in all lanes -> scalar registers
-__device__ __forceinline__ uint64_t uni64(uint64_t v) {
-  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-}
-__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-// per lane: bit `lane` of the scalar mask m ? a : b   (one v_cndmask with an SGPR-pair condition, no per-lane shift)
-__device__ __forceinline__ uint32_t sel(uint64_t m, uint32_t a, uint32_t b) {
-  uint32_t r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
-  return r;
-}
-#define ROWS_DPP(v, ctrl, rowmask) (uint32_t) __builtin_amdgcn_update_dpp((int)(v), (int)(v), ctrl, rowmask, 0xF, false)
+struct Row3 { uint32_t h, a, b; };   // columns x0-4 .. x0-1 at bits 28..31 of h, x0 .. x0+31 in a, x0+32 .. x0+63 in b
 
-// Every lane of a run takes the run's minimum.  L: bit x = lane x is linked to lane x - 1 (bit 0 is clear); lanes outside runs
-// keep their value.  Forward inclusive min-scan (row_shr 1, 2, 4, 8 inside the 16-lane rows, row_bcast 15 / 31 across them), each
-// step predicated by "the link bits between source and destination are all set" — masks made on the scalar unit by doubling —
-// then the same backwards (row_shl, and v_readlane of lanes 48 / 32 / 16 for the row boundaries, top row first).
-__device__ __forceinline__ uint32_t seg_run_min(uint32_t v, uint64_t L) {
-  constexpr uint64_t R1 = 0xFFFEFFFEFFFEFFFEull, R2 = 0xFFFCFFFCFFFCFFFCull, R4 = 0xFFF0FFF0FFF0FFF0ull, R8 = 0xFF00FF00FF00FF00ull;
+__device__ __forceinline__ Row3 operator|(Row3 x, Row3 y) { return {x.h | y.h, x.a | y.a, x.b | y.b}; }
+__device__ __forceinline__ Row3 operator&(Row3 x, Row3 y) { return {x.h & y.h, x.a & y.a, x.b & y.b}; }
+__device__ __forceinline__ Row3 operator^(Row3 x, Row3 y) { return {x.h ^ y.h, x.a ^ y.a, x.b ^ y.b}; }
+__device__ __forceinline__ Row3 andn(Row3 x, Row3 y) { return {x.h & ~y.h, x.a & ~y.a, x.b & ~y.b}; }
+__device__ __forceinline__ bool any(Row3 x) { return (x.h | x.a | x.b) != 0u; }
+template <int K> __device__ __forceinline__ Row3 shl(Row3 v) {      // towards larger x
+  return {v.h << K, __builtin_amdgcn_alignbit(v.a, v.h, 32 - K), __builtin_amdgcn_alignbit(v.b, v.a, 32 - K)};
+}
+template <int K> __device__ __forceinline__ Row3 shr(Row3 v) {      // towards smaller x; cells left of column x0 - 4 do not exist
+  return {__builtin_amdgcn_alignbit(v.a, v.h, K) & 0xF0000000u, __builtin_amdgcn_alignbit(v.b, v.a, K), v.b >> K};
+}
+// v | v << 1 | .. | v << 4 by doubling; x: the same without v itself
+__device__ __forceinline__ void dil_r(Row3 v, Row3 &all, Row3 &x) { Row3 y = v | shl<1>(v); y = y | shl<2>(y); x = shl<1>(y); all = v | x; }
+__device__ __forceinline__ void dil_l(Row3 v, Row3 &all, Row3 &x) { Row3 y = v | shr<1>(v); y = y | shr<2>(y); x = shr<1>(y); all = v | x; }
+// the row above / below arrives (zero into the first / last lane).  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t dn1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
+__device__ __forceinline__ uint32_t up1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1
+__device__ __forceinline__ Row3 row_dn(Row3 v) { return {dn1(v.h), dn1(v.a), dn1(v.b)}; }
+__device__ __forceinline__ Row3 row_up(Row3 v) { return {up1(v.h), up1(v.a), up1(v.b)}; }
+// OR over dv = 1 .. 4 of the rows dv above (DN) / below, by doubling
+template <bool DN> __device__ __forceinline__ Row3 vert4(Row3 v) {
+  if (DN) { const Row3 t1 = v | row_dn(v); const Row3 t2 = t1 | row_dn(row_dn(t1)); return row_dn(t2); }
+  const Row3 t1 = v | row_up(v); const Row3 t2 = t1 | row_up(row_up(t1)); return row_up(t2);
+}
+__device__ __forceinline__ Row3 rev(Row3 v) { return {__builtin_bitreverse32(v.b), __builtin_bitreverse32(v.a), __builtin_bitreverse32(v.h)}; }
+// all bits of the runs of c that hold a bit of s (s subset of c), from the lowest such bit upwards: c + s ripples through a run
+__device__ __forceinline__ Row3 fill_up(Row3 c, Row3 s) {
+  uint32_t c1, c2, c3;
+  Row3 t;
+  t.h = __builtin_addc(c.h, s.h, 0u, &c1);
+  t.a = __builtin_addc(c.a, s.a, c1, &c2);
+  t.b = __builtin_addc(c.b, s.b, c2, &c3);
+  return ((t ^ c) & c) | s;
+}
+__device__ __forceinline__ int popc3(Row3 v) { return __popc(v.h) + __popc(v.a) + __popc(v.b); }
+
+// the F32 of lane l (v_readlane moves bit patterns; the builtin is typed int)
+__device__ __forceinline__ float lane_f32(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
+__device__ __forceinline__ float wave_fmin(float v) {
+  v = fminf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0xB1))); v = fminf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0x4E)));
+  v = fminf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0x141))); v = fminf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0x140)));
+  const float a = lane_f32(v, 0), b = lane_f32(v, 16), c = lane_f32(v, 32), d = lane_f32(v, 48);
+  return fminf(fminf(a, b), fminf(c, d));
+}
+__device__ __forceinline__ float wave_fmax(float v) {
+  v = fmaxf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0xB1))); v = fmaxf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0x4E)));
+  v = fmaxf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0x141))); v = fmaxf(v, __uint_as_float(MOD_DPP(__float_as_uint(v), 0x140)));
+  const float a = lane_f32(v, 0), b = lane_f32(v, 16), c = lane_f32(v, 32), d = lane_f32(v, 48);
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+// sum over lanes 0 .. 31 (the grid rows live in lanes 0 .. 19)
+__device__ __forceinline__ int wave_sum_lo32(int v) {
+  v += (int)MOD_DPP(v, 0xB1); v += (int)MOD_DPP(v, 0x4E); v += (int)MOD_DPP(v, 0x141); v += (int)MOD_DPP(v, 0x140);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
+}
+__device__ __forceinline__ uint64_t lane_bits(uint32_t lo, uint32_t hi, int l) {   // words of lane l as one scalar mask
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, l);
+}
+
+constexpr int kTilesPerBlock = 4;
+
+__global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClArgs a, int tiles_x, int tiles_y) {
+  const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+  const int wi = blockIdx.x * kTilesPerBlock + wv, ty = blockIdx.y, f = blockIdx.z;
+  if (wi >= tiles_x) return;
+  const size_t tix = (size_t)f * tiles_y * tiles_x + (size_t)ty * tiles_x + wi;
+  int *hdr = a.tilehdr + tix * 2;
+  if (__builtin_amdgcn_readfirstlane(hdr[0]) == 0) return;          // no dynamic pixel in the tile
+  const int x0 = wi * 64, y0 = ty * TH, MW = c.mask_words, W = c.W, H = c.H;
+  const size_t N = (size_t)W * H, fN = (size_t)f * N;
+  // ---- the mask words of the 20 grid rows, lane = row -------------------------------------------------------------------------
+  Row3 M;
   {
-    const uint64_t p2 = L & (L << 1), p4 = p2 & (p2 << 2), p8 = p4 & (p4 << 4);
-    uint32_t t;
-    t = ROWS_DPP(v, 0x111, 0xF); v = sel(L & R1, min(v, t), v);
-    t = ROWS_DPP(v, 0x112, 0xF); v = sel(p2 & R2, min(v, t), v);
-    t = ROWS_DPP(v, 0x114, 0xF); v = sel(p4 & R4, min(v, t), v);
-    t = ROWS_DPP(v, 0x118, 0xF); v = sel(p8 & R8, min(v, t), v);
-    // A: all link bits from the start of the lane's 16-lane row up to the lane are set
-    uint64_t A = L & ((L << 1) | ~R1);
-    A &= (A << 2) | ~R2; A &= (A << 4) | ~R4; A &= (A << 8) | ~R8;
-    t = ROWS_DPP(v, 0x142, 0xA); v = sel(A & 0xFFFF0000FFFF0000ull, min(v, t), v);             // row_bcast:15 into rows 1 and 3
-    const uint64_t a31 = (A & 0x0000FFFF00000000ull) | (((A >> 47) & 1ull) ? (A & 0xFFFF000000000000ull) : 0ull);
-    t = ROWS_DPP(v, 0x143, 0xC); v = sel(a31, min(v, t), v);                                   // row_bcast:31 into rows 2 and 3
-  }
-  {
-    constexpr uint64_t S1 = 0x7FFF7FFF7FFF7FFFull, S2 = 0x3FFF3FFF3FFF3FFFull, S4 = 0x0FFF0FFF0FFF0FFFull, S8 = 0x00FF00FF00FF00FFull;
-    const uint64_t Rr = L >> 1;                          // bit x: lane x is linked to lane x + 1
-    const uint64_t q2 = Rr & (Rr >> 1), q4 = q2 & (q2 >> 2), q8 = q4 & (q4 >> 4);
-    uint32_t t;
-    t = ROWS_DPP(v, 0x101, 0xF); v = sel(Rr & S1, min(v, t), v);
-    t = ROWS_DPP(v, 0x102, 0xF); v = sel(q2 & S2, min(v, t), v);
-    t = ROWS_DPP(v, 0x104, 0xF); v = sel(q4 & S4, min(v, t), v);
-    t = ROWS_DPP(v, 0x108, 0xF); v = sel(q8 & S8, min(v, t), v);
-    // B: all link bits from the lane to the first lane of the next 16-lane row are set
-    uint64_t B = Rr & ((Rr >> 1) | ~S1);
-    B &= (B >> 2) | ~S2; B &= (B >> 4) | ~S4; B &= (B >> 8) | ~S8;
-    uint32_t s;
-    s = (uint32_t)__builtin_amdgcn_readlane((int)v, 48); v = sel(B & 0x0000FFFF00000000ull, min(v, s), v);
-    s = (uint32_t)__builtin_amdgcn_readlane((int)v, 32); v = sel(B & 0x00000000FFFF0000ull, min(v, s), v);
-    s = (uint32_t)__builtin_amdgcn_readlane((int)v, 16); v = sel(B & 0x000000000000FFFFull, min(v, s), v);
-  }
-  return v;
-}
-
-#ifndef ROWS_TPW
-#define ROWS_TPW 1     // tiles (= waves) per workgroup; the waves of a workgroup share nothing
-#endif
-template <bool N4>
-__global__ __launch_bounds__(64 * ROWS_TPW) void k_ccl_rows(DevCam c, ClArgs a) {
-  // (the depth of the grid is NOT kept in LDS: the window pass reads the few depths it needs from global memory — cache hits, the
-  // tile's rows were loaded a moment ago — so that a wave holds 2.8 KB of LDS instead of 8.2 and eight waves fit a SIMD)
-  __shared__ uint16_t LABs[ROWS_TPW][PH * PW];   // labels: cell id (r * PW + j) of the smallest cell of the set, | kHaloBit for halo cells
-  const int lane = threadIdx.x, wv_ = ROWS_TPW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.y) : 0;
-  uint16_t *const LAB = LABs[wv_];
-  const int tiles_x = c.mask_words;
-  const int wi = blockIdx.x * ROWS_TPW + wv_, x0 = wi * 64, y0 = blockIdx.y * TH, f = blockIdx.z;
-  if (ROWS_TPW > 1 && wi >= tiles_x) return;
-  const int MW = c.mask_words, n = N4 ? 4 : c.n;        // n <= 4; the default 4 has its own instance (constant window bounds)
-  const size_t N = (size_t)c.W * c.H, fN = (size_t)f * N;
-  int *hdr = a.tilehdr + ((size_t)f * gridDim.y * tiles_x + (size_t)blockIdx.y * tiles_x + wi) * 2;
-  if (__builtin_amdgcn_readfirstlane(hdr[0]) == 0) return;          // no dynamic pixel in the tile: one scalar load
-  const float th = c.depth_th;
-#ifdef MOD_PHASE_COUNTERS   // diagnostic build only (make PHASE_COUNTERS=1, tools/dbg_rows_counters.py): event counts and cycles per tile
-  unsigned long long rc_[16] = {};
-  const unsigned long long rt0_ = clock64();
-  unsigned long long rt1_ = rt0_;
-#define RCOUNT(i, v) rc_[i] += (unsigned long long)(v);
-#define RSTAMP(i) { const unsigned long long t_ = clock64(); rc_[i] += t_ - rt1_; rt1_ = t_; }
-#else
-#define RCOUNT(i, v)
-#define RSTAMP(i)
-#endif
-  // Per-row scalars (dynamic bits, link masks, ...) live in VGPR LANES: lane r of these registers belongs to grid row r.  A row's
-  // value is fetched with v_readlane (lane index in an SGPR: the row loops stay rolled) — no LDS round trip, which is what a
-  // single wave cannot hide.
-  uint32_t mLlo = 0, mLhi = 0, mVlo = 0, mVhi = 0, mUlo = 0, mUhi = 0, mRlo = 0, mRhi = 0;
-  auto rd32 = [&](uint32_t v, int r) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, r); };
-  auto rd64 = [&](uint32_t lo, uint32_t hi, int r) -> uint64_t { return ((uint64_t)rd32(hi, r) << 32) | (uint64_t)rd32(lo, r); };
-  // (no writelane builtin in this compiler; value and lane index are scalars.  The s_nop covers the wait states a VALU-written
-  // SGPR needs before it may select a lane — inline asm is opaque to the hazard recogniser)
-  auto wr32 = [&](uint32_t &v, int r, uint32_t x) {   // one SGPR operand per VALU instruction: the lane index goes through M0 (saved / restored)
-    uint32_t keep;
-    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(v), "=&s"(keep) : "s"(x), "s"(r));
-  };
-  // ---- all HBM reads in one round trip: mask words (lane r reads row r's), depth rows ----
-  uint64_t q0 = 0ull;
-  uint32_t mH = 0u;                                                  // dynamic bits of the 4 left-halo columns (bit j = column x0 - 4 + j)
-  if (lane < PH) {
     const int gy = y0 - HL + lane;
-    const bool inrow = gy >= 0 && gy < c.H && lane >= HL - n;
-    const uint64_t *mr = a.mask + ((size_t)f * c.H + (inrow ? gy : 0)) * MW;
-    q0 = inrow ? mr[wi] : 0ull;
-    const uint64_t qL = (inrow && wi > 0) ? mr[wi - 1] : 0ull;
-    mH = (uint32_t)(qL >> 60) & (0xFu << (HL - n)) & 0xFu;          // only the n nearest columns can be window cells
+    const bool inrow = lane < PH && gy >= 0 && gy < H;
+    const uint64_t *mr = a.mask + ((size_t)f * H + (inrow ? gy : 0)) * MW;
+    const uint64_t q0 = mr[wi], qL = mr[max(wi - 1, 0)];              // unconditional loads, clamped addresses
+    M.h = (inrow && wi > 0) ? ((uint32_t)(qL >> 32) & 0xF0000000u) : 0u;
+    M.a = inrow ? (uint32_t)q0 : 0u;
+    M.b = inrow ? (uint32_t)(q0 >> 32) : 0u;
   }
-  const uint32_t mMlo = (uint32_t)q0, mMhi = (uint32_t)(q0 >> 32);   // dynamic bits of the 64 tile columns
-  float zr[PH];
+  // ---- can a depth gate fire?  Not when the dynamic cells of the grid span at most depth_diff: |z_p - z_q| <= max - min for every
+  // pair, and F32 subtraction is monotone.  NaN depths link with everything (`!(NaN > th)`) and are left out of the range. -------
   {
-    const int xc = min(x0 + lane, c.W - 1);
+    const float qnan = __uint_as_float(0x7fc00000u);
+    float zmin = qnan, zmax = qnan;
+    // (uniform row base + 32-bit lane offset: the `global_load v, v_off, s[base]` form, no 64-bit address arithmetic per lane)
+    const uint32_t oc = 4u * (uint32_t)min(x0 + lane, W - 1), oh = 4u * (uint32_t)max(x0 - HL + min(lane, HL - 1), 0);
+    constexpr int HB = PH / 2;                                         // two batches of 10 rows: 20 loads in flight
 #pragma unroll
-    for (int r = 0; r < PH; r++) {
-      const int gy = min(max(y0 - HL + r, 0), c.H - 1);
-      zr[r] = a.z[fN + (size_t)gy * c.W + xc];
+    for (int g0 = 0; g0 < PH; g0 += HB) {
+      float zr[HB], zh[HB];
+#pragma unroll
+      for (int i = 0; i < HB; i++) {
+        const int gy = min(max(y0 - HL + g0 + i, 0), H - 1);
+        const char *row = (const char *)(a.z + fN + (size_t)gy * W);
+        zr[i] = *(const float *)(row + oc);
+        zh[i] = *(const float *)(row + oh);
+      }
+#pragma unroll
+      for (int i = 0; i < HB; i++) {
+        const int gr = g0 + i;
+        const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(M.a, M.b, gr));
+        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)M.h, gr) >> 28));
+        const float z1 = dyn ? zr[i] : qnan, z2 = hdyn ? zh[i] : qnan;
+        zmin = fminf(zmin, fminf(z1, z2));
+        zmax = fmaxf(zmax, fmaxf(z1, z2));
+      }
+    }
+    zmin = wave_fmin(zmin); zmax = wave_fmax(zmax);
+    if (zmax - zmin > c.depth_th) {                                   // wave-uniform: leave the tile to the union-find kernel
+      if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;
+      return;
     }
   }
-  // ---- setup: grid into LDS; link masks of the two pre-linked positions (left, up); labels = first cell of the pixel's run ----
+  // ---- per-row facts ---------------------------------------------------------------------------------------------------------------
+  const bool il = lane >= HL && lane < PH;                             // a tile row
+  Row3 drA, drX, dlA, dlX;
+  dil_r(M, drA, drX);
+  dil_l(M, dlA, dlX);
+  const Row3 above = vert4<true>(drA);                                 // cells that have a dynamic cell up-left in one of the 4 rows above
+  const Row3 UL = M & (drX | above);                                   // has an up-left edge
+  const Row3 E = UL | (M & (dlX | vert4<false>(dlA)));                 // has any edge
+  Row3 C;                                                              // M with gaps of <= 3 cells closed: one run = one chain of same-row links
   {
-    uint64_t Mprev = 0ull;
-    float zprev = 0.0f;
-#pragma unroll
-    for (int r = 0; r < PH; r++) {
-      const uint64_t Mr = rd64(mMlo, mMhi, r);
-      const uint32_t Hr = rd32(mH, r);
-      const float zc = zr[r];
-      if (lane < HL) {
-        LAB[r * PW + lane] = (uint16_t)(((Hr >> lane) & 1u) ? (uint32_t)(kHaloBit | (r * PW + lane)) : kNoLabel);
-      }
-      uint32_t lab = kNoLabel;
-      if (Mr) {                                                      // wave-uniform
-        const float zl = __uint_as_float(ROWS_DPP(__float_as_uint(zc), 0x138, 0xF));    // wave_shr:1
-        const uint64_t L1 = Mr & (Mr << 1) & __ballot(!(fabsf(zc - zl) > th));         // depthDiff gate (clusterer_nodelet.cpp:194); a NaN links
-        const uint64_t Vr = Mprev ? (Mr & Mprev & __ballot(!(fabsf(zc - zprev) > th))) : 0ull;
-        const uint64_t starts = Mr & ~L1;
-        const int s = 63 - __clzll((long long)(starts & (~0ull >> (63 - lane))));
-        if ((Mr >> lane) & 1ull) lab = (uint32_t)(r * PW + HL + s) | (r < HL ? (uint32_t)kHaloBit : 0u);
-        wr32(mLlo, r, (uint32_t)L1); wr32(mLhi, r, (uint32_t)(L1 >> 32));
-        wr32(mVlo, r, (uint32_t)Vr); wr32(mVhi, r, (uint32_t)(Vr >> 32));
-        wr32(mUlo, r, (uint32_t)(L1 | Vr)); wr32(mUhi, r, (uint32_t)((L1 | Vr) >> 32));
-      }
-      LAB[r * PW + HL + lane] = (uint16_t)lab;
-      Mprev = Mr; zprev = zc;
-    }
+    const Row3 l1 = M | shl<1>(M), l2 = l1 | shl<2>(M), l3 = l2 | shl<3>(M), l4 = l3 | shl<4>(M);
+    C = (l4 & M) | (l3 & shr<1>(M)) | (l2 & shr<2>(M)) | (l1 & shr<3>(M)) | (M & shr<4>(M));
   }
-  asm volatile("" ::: "memory");           // one wave: its LDS operations execute in order; only the compiler must not reorder them
-  RSTAMP(12)
-  // depth of grid cell (row r, column j) from global memory; cells outside the image are never dynamic, their value is not used
-  auto zcell = [&](int r, int j) -> float {
-    const int gy = min(max(y0 - HL + r, 0), c.H - 1), gx = min(max(x0 - HL + j, 0), c.W - 1);
-    return a.z[fN + (size_t)gy * c.W + gx];
-  };
-  // ---- sweeps: row r takes the labels straight above (below) its vertically linked pixels, then its runs are levelled ----
-  auto sweep = [&](const bool down, const bool force) -> bool {
-    bool changed = false;
-    uint32_t carry = kNoLabel;
-    const int step = down ? 1 : -1;
-    int r = down ? 0 : PH - 1;
-    uint32_t nextv = LAB[r * PW + HL + lane];
-#pragma unroll 1
-    for (int i = 0; i < PH; i++, r += step) {
-      const uint32_t cur = nextv;
-      if (i + 1 < PH) nextv = LAB[(r + step) * PW + HL + lane];      // the next row's labels are on their way while this row is worked on
-      const uint64_t M = rd64(mMlo, mMhi, r);
-      if (M == 0) continue;                                          // no link can involve this row: the carry is not looked at
-      RCOUNT(3, 1)
-      const int vr = down ? r : r + 1;
-      const uint64_t V = (i == 0) ? 0ull : rd64(mVlo, mVhi, vr);
-      uint32_t nv = cur;
-      if (V) nv = min(cur, sel(V, carry, kNoLabel));
-      if (force || __ballot(nv != cur)) {
-        const uint64_t L = rd64(mLlo, mLhi, r);
-        if (L) {
-          const uint32_t pv = ROWS_DPP(nv, 0x138, 0xF);
-          if (__ballot(nv != pv) & L) { nv = seg_run_min(nv, L); RCOUNT(4, 1) }
-        }
-        if (__ballot(nv != cur)) {
-          LAB[r * PW + HL + lane] = (uint16_t)nv;
-          changed = true;
-        }
-      }
-      carry = nv;
-    }
-    asm volatile("" ::: "memory");
-    return changed;
-  };
-  // ---- the other window positions: verify, collect "has an up-left edge", unite where labels still differ ----
-  auto window_pass = [&]() -> bool {
-    bool changed = false;
-#pragma unroll 1
-    for (int r = HL; r < PH; r++) {
-      const uint64_t M = rd64(mMlo, mMhi, r);
-      if (M == 0) continue;
-      RCOUNT(5, 1)
-      uint64_t U = rd64(mUlo, mUhi, r);
-      uint32_t cur = LAB[r * PW + HL + lane];
-      const uint32_t cur0 = cur;
-      // the labels of all window cells in ONE round trip (cell (r - dv, x - k) for lane x; lanes x < k reach the left-halo columns)
-      uint32_t lq[5][5];
-#pragma unroll
-      for (int dv = 0; dv <= 4; dv++)
-#pragma unroll
-        for (int k = 0; k <= 4; k++)
-          if ((dv | k) != 0 && (N4 || (dv <= n && k <= n))) lq[dv][k] = LAB[(r - dv) * PW + HL + lane - k];
-      uint64_t Mq[5];
-      uint32_t Hq[5];
-#pragma unroll
-      for (int dv = 0; dv <= 4; dv++) { Mq[dv] = (N4 || dv <= n) ? rd64(mMlo, mMhi, r - dv) : 0ull; Hq[dv] = (N4 || dv <= n) ? rd32(mH, r - dv) : 0u; }
-      // candidates of a position: pixel (r, x) and cell (r - dv, x - k) both dynamic
-      auto cand = [&](int dv, int k) -> uint64_t { return M & ((Mq[dv] << k) | (uint64_t)(Hq[dv] >> (HL - k))); };
-      // pass 1 (no depth read): which positions still matter — a candidate pair with two labels, or a pixel still lacking its edge
-      uint32_t need = 0;
-#pragma unroll
-      for (int dv = 0; dv <= 4; dv++)
-#pragma unroll
-        for (int k = 0; k <= 4; k++) {
-          if ((dv | k) == 0 || !(N4 || (dv <= n && k <= n))) continue;
-          const uint64_t C = cand(dv, k);
-          if (C == 0) continue;
-          RCOUNT(6, 1)
-          if ((__ballot(lq[dv][k] != cur) & C) | (C & ~U)) need |= 1u << (dv * 5 + k);
-        }
-      if (need == 0) continue;
-      const float zp = zcell(r, HL + lane);
-      float zq[5][5];
-#pragma unroll
-      for (int dv = 0; dv <= 4; dv++)
-#pragma unroll
-        for (int k = 0; k <= 4; k++)
-          if ((dv | k) != 0 && (N4 || (dv <= n && k <= n))) zq[dv][k] = zcell(r - dv, HL + lane - k);
-#pragma unroll
-      for (int dv = 0; dv <= 4; dv++)
-#pragma unroll
-        for (int k = 0; k <= 4; k++) {
-          if ((dv | k) == 0 || !(N4 || (dv <= n && k <= n))) continue;
-          if (!((need >> (dv * 5 + k)) & 1u)) continue;
-          const uint64_t C = cand(dv, k);
-          const uint64_t differ = __ballot(lq[dv][k] != cur) & C;
-          if (differ == 0 && (C & ~U) == 0) continue;                 // an earlier position of this row has settled it
-          RCOUNT(7, 1)
-          const uint64_t E = C & __ballot(!(fabsf(zp - zq[dv][k]) > th));
-          U |= E;
-          if (E & differ) {                                           // a link between two labels: both ends take the smaller (rare)
-            RCOUNT(8, 1)
-            const int qi = (r - dv) * PW + HL + lane - k;
-            const uint32_t fresh = LAB[qi];                           // the cell as it is NOW (another lane of this row may have lowered it)
-            const uint32_t m = min(cur, fresh);
-            const bool in = (E >> lane) & 1ull;
-            const bool tgt = in && fresh != m, me = in && cur != m;
-            if (tgt) LAB[qi] = (uint16_t)m;
-            if (me) cur = m;
-            // a left-halo cell that still carried its own id has no dependants: lowering it needs no further round
-            if (__ballot(me || (tgt && !(lane < k && (fresh & kHaloBit))))) changed = true;
-            asm volatile("" ::: "memory");
-          }
-        }
-      if (cur < cur0) LAB[r * PW + HL + lane] = (uint16_t)cur;        // per lane: a cell lowered through LDS by another lane keeps that value
-      wr32(mUlo, r, (uint32_t)U); wr32(mUhi, r, (uint32_t)(U >> 32));
-      asm volatile("" ::: "memory");
-    }
-    return changed;
-  };
-  {
-    bool force = false;
-    while (true) {
-      // down / up until a sweep finds nothing to change.  The first down sweep of a round does not count: after the window pass has
-      // lowered single cells, rows ABOVE them are reached only by the up sweep — and the links among the halo rows are verified by
-      // nobody else (the window pass looks at the windows of tile pixels only).
-      bool first = true;
-      RCOUNT(1, 1)
-      while (true) {
-        const bool d = sweep(true, force);
-        RCOUNT(2, 1)
-        force = false;
-        if (!d && !first) break;
-        first = false;
-        RCOUNT(2, 1)
-        if (!sweep(false, false)) break;
-      }
-      RSTAMP(13)
-      const bool w_ = window_pass();
-      RSTAMP(14)
-      if (!w_) break;
-      force = true;                       // labels were lowered cell by cell: runs must be levelled again
-    }
-  }
-  // ---- publish: parent[p] = tile root, root bits ----
-#pragma unroll 1
-  for (int r = HL; r < PH; r++) {
-    const int gy = y0 + r - HL;
-    const uint64_t M = rd64(mMlo, mMhi, r);
-    uint64_t rb = 0ull;
-    if (M) {
-      const uint32_t cur = LAB[r * PW + HL + lane];
-      const bool dyn = (M >> lane) & 1ull;
-      if (dyn) {
-        const int rr = (int)cur / PW, cc = (int)cur - rr * PW;
-        const int rg = (y0 + rr - HL) * c.W + x0 + cc - HL;
-        if (MOD_CHECK(a, rr >= HL && rr < PH && cc >= HL && cc < PW && rg >= 0 && (size_t)rg < N, 13))
-          a.parent[fN + (size_t)gy * c.W + x0 + lane] = rg;
-      }
-      rb = __ballot(dyn && cur == (uint32_t)(r * PW + HL + lane));
-      wr32(mRlo, r, (uint32_t)rb); wr32(mRhi, r, (uint32_t)(rb >> 32));
-    }
-    if (lane == 0 && gy < c.H) a.lroot[((size_t)f * c.H + gy) * MW + wi] = rb;
-  }
-  // ---- per tile root: member count and first_edge_key (smallest raster index of a member with an up-left edge) ----
-#pragma unroll 1
-  for (int r0 = HL; r0 < PH; r0++) {
-    uint64_t rb = rd64(mRlo, mRhi, r0);
-    while (rb) {                                                     // wave-uniform
-      const int b = __builtin_ctzll(rb);
-      rb &= rb - 1ull;
-      const uint32_t R = (uint32_t)(r0 * PW + HL + b);
-      RCOUNT(9, 1)
-      int size = 0, key = kKeyNone;
-      uint32_t nextv = LAB[r0 * PW + HL + lane];
-#pragma unroll 1
-      for (int r = r0; r < PH; r++) {                                // the root is the set's first cell in raster order
-        const uint32_t v = nextv;
-        if (r + 1 < PH) nextv = LAB[(r + 1) * PW + HL + lane];
-        const uint64_t M = rd64(mMlo, mMhi, r);
-        if (M == 0) continue;
-        const uint64_t eq = __ballot(v == R) & M;
-        size += __popcll((unsigned long long)eq);
-        if (key == kKeyNone) {
-          const uint64_t e = eq & rd64(mUlo, mUhi, r);
-          if (e) key = (y0 + r - HL) * c.W + x0 + __builtin_ctzll(e);
-        }
-      }
-      if (lane == 0) {
-        const size_t rg = fN + (size_t)(y0 + r0 - HL) * c.W + x0 + b;
-        a.rsize[rg] = size; a.rkey[rg] = key;
-      }
-    }
-  }
-  // ---- link requests: a halo cell that ended up in a set with a tile pixel (its label is a tile cell) belongs to another tile,
-  // whose root is not known yet -> (halo pixel, tile root) for k_ccl_link; a cell whose left / upper neighbour is a halo cell of
-  // the same set with a direct link leaves it to that neighbour (that link is one the tile owning the cell sees itself) ----
+  const Row3 rC = rev(C);
+  Row3 R = {0u, il ? (M.a & E.a) : 0u, il ? (M.b & E.b) : 0u};         // tile pixels with an edge that no component holds yet
+  const uint32_t Za = il ? (M.a & ~E.a) : 0u, Zb = il ? (M.b & ~E.b) : 0u;   // tile pixels without any edge: roots of their own
+  uint32_t rootA = Za, rootB = Zb;
   int nreq = 0;
-  uint2 *req = a.requests + ((size_t)f * gridDim.y * tiles_x + (size_t)blockIdx.y * tiles_x + wi) * a.req_cap;
-  auto emit = [&](bool want, int hg, uint32_t lab) {
-    const uint64_t wb = __ballot(want);
-    if (wb == 0) return;
-    if (want) {
-      const int slot = nreq + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(wb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wb, 0u));
-      const int rr = (int)lab / PW, cc = (int)lab - rr * PW;
-      const int rg = (y0 + rr - HL) * c.W + x0 + cc - HL;
-      if (MOD_CHECK(a, slot >= 0 && slot < a.req_cap, 12) && MOD_CHECK(a, rg >= 0 && (size_t)rg < N && hg >= 0 && (size_t)hg < N, 13))
-        req[slot] = make_uint2((uint32_t)hg, (uint32_t)rg);
-    }
-    nreq += __popcll((unsigned long long)wb);
-  };
-#pragma unroll 1
-  for (int r = HL - n; r < HL; r++) {                                // the rows above the tile, columns x0 .. x0 + 63
-    const uint64_t M = rd64(mMlo, mMhi, r);
-    if (M == 0) continue;
-    const uint32_t lab = LAB[r * PW + HL + lane];
-    const uint64_t covered = rd64(mLlo, mLhi, r) | rd64(mVlo, mVhi, r);
-    const bool want = (((M & ~covered) >> lane) & 1ull) && !(lab & kHaloBit);
-    emit(want, (y0 - HL + r) * c.W + x0 + lane, lab);
+  uint2 *req = a.requests + tix * a.req_cap;
+  // one component by inspection?  Every non-empty row is ONE closed run whose cells all have an edge, and every non-empty row
+  // but the first has a link to a row above: by induction over the rows all dynamic cells of the grid are connected.
+  bool single;
+  {
+    const uint64_t ne = __ballot(any(M));
+    const int first = __builtin_ctzll(ne);                              // ne != 0: the tile has a dynamic pixel
+    const Row3 starts = andn(C, shl<1>(C));
+    const bool ok = !any(M) || (popc3(starts) == 1 && !any(E ^ M) && (lane == first || any(M & above)));
+    single = __ballot(!ok) == 0ull && __ballot(any(R)) != 0ull;
   }
-  if (__ballot(mH != 0u)) {                                          // any dynamic cell in the 4 columns to the left (all 20 rows)?
-#pragma unroll 1
-    for (int i0 = 0; i0 < PH * HL; i0 += 64) {
-      const int i = i0 + lane, r = min(i >> 2, PH - 1), j = i & 3;
-      // lane i needs row r's bits: mH holds them in lane r -> one cross-lane read (ds_bpermute; this loop runs twice per tile)
-      const uint32_t hr = (uint32_t)__shfl((int)mH, r), hu = (uint32_t)__shfl((int)mH, max(r - 1, 0));
-      bool want = false;
-      uint32_t lab = kNoLabel;
-      if (i < PH * HL && ((hr >> j) & 1u)) {
-        lab = LAB[r * PW + j];
-        if (!(lab & kHaloBit)) {
-          const float zme = zcell(r, j);
-          const bool cov_up = r > 0 && ((hu >> j) & 1u) && LAB[(r - 1) * PW + j] == lab && !(fabsf(zme - zcell(r - 1, j)) > th);
-          const bool cov_left = j > 0 && ((hr >> (j - 1)) & 1u) && LAB[r * PW + j - 1] == lab && !(fabsf(zme - zcell(r, j - 1)) > th);
-          want = !(cov_up || cov_left);
-        }
+  for (;;) {                                                           // wave-uniform loop over the components with a tile pixel
+    const uint64_t rrows = __ballot(any(R));
+    if (rrows == 0ull) break;
+    Row3 S;
+    if (single) S = M;
+    else {
+      const int sr = __builtin_ctzll(rrows);                           // first pixel in raster order of what is left: the seed
+      const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)R.a, sr), sb = (uint32_t)__builtin_amdgcn_readlane((int)R.b, sr);
+      const uint32_t ba = sa & (0u - sa), bb = sa ? 0u : (sb & (0u - sb));
+      S = {0u, lane == sr ? ba : 0u, lane == sr ? bb : 0u};
+      for (;;) {                                                       // flood: S only grows, inside M
+        Row3 rA, rX, lA, lX;
+        dil_r(S, rA, rX);
+        dil_l(S, lA, lX);
+        const Row3 reach = M & (rA | lA | vert4<true>(rA) | vert4<false>(lA));
+        const Row3 S2 = (fill_up(C, reach) | rev(fill_up(rC, rev(reach)))) & M;
+        const bool grew = any(S2 ^ S);
+        S = S2;
+        if (__ballot(grew) == 0ull) break;
       }
-      emit(want, (y0 - HL + r) * c.W + x0 - HL + j, lab);
+    }
+    // ---- publish the component ----
+    const uint64_t irows = __ballot(il && (S.a | S.b) != 0u);
+    const int rr = __builtin_ctzll(irows);                              // S holds a tile pixel (its seed, or R != 0)
+    const uint32_t fa = (uint32_t)__builtin_amdgcn_readlane((int)S.a, rr), fb = (uint32_t)__builtin_amdgcn_readlane((int)S.b, rr);
+    const int rcol = fa ? __builtin_ctz(fa) : 32 + __builtin_ctz(fb);
+    const int rootg = (y0 + rr - HL) * W + x0 + rcol;                  // the component's first tile pixel in raster order
+    if (lane == rr) { if (rcol < 32) rootA |= 1u << rcol; else rootB |= 1u << (rcol - 32); }
+#pragma unroll
+    for (int j = 0; j < TH; j++) {
+      const uint64_t bitsj = lane_bits(S.a, S.b, HL + j);
+      if (bitsj != 0ull && __builtin_amdgcn_inverse_ballot_w64(bitsj))
+        *(int *)((char *)(a.parent + fN + (size_t)(y0 + j) * W + x0) + 4u * (uint32_t)lane) = rootg;
+    }
+    {
+      const int cnt = il ? __popc(S.a) + __popc(S.b) : 0;
+      const uint32_t ka = S.a & UL.a, kb = S.b & UL.b;
+      uint32_t key = (uint32_t)kKeyNone;
+      if (il && (ka | kb)) key = (uint32_t)((y0 + lane - HL) * W + x0 + (ka ? __builtin_ctz(ka) : 32 + __builtin_ctz(kb)));
+      const int size = wave_sum_lo32(cnt);
+      key = wave_min_u32(key);
+      if (lane == 0) { a.rsize[fN + rootg] = size; a.rkey[fN + rootg] = (int)key; }
+    }
+    // halo cells of the component belong to other tiles: one link request (halo cell, root) per group of halo cells that are
+    // direct neighbours (a cell whose left or upper neighbour is a halo cell of the set leaves it to that neighbour: the edge
+    // between them is seen by the tile that owns the cell) — k_ccl_tile's rule
+    {
+      const Row3 HS = {S.h, lane < HL ? S.a : 0u, lane < HL ? S.b : 0u};
+      const Row3 em = andn(HS, shl<1>(HS) | row_dn(HS));
+      uint64_t todo = __ballot(any(em));
+      while (todo) {                                                   // wave-uniform: the few grid rows that emit
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint64_t eb = lane_bits(em.a, em.b, l);
+        const uint32_t eh = (uint32_t)__builtin_amdgcn_readlane((int)em.h, l) >> 28;
+        const int hgrow = (y0 - HL + l) * W + x0;
+        if (__builtin_amdgcn_inverse_ballot_w64((uint64_t)eh)) {       // left-halo columns x0 - 4 + lane, lanes 0 .. 3
+          const int slot = nreq + __popc(eh & ((1u << lane) - 1u));
+          if (MOD_CHECK(a, slot < a.req_cap, 12)) req[slot] = make_uint2((uint32_t)(hgrow - HL + lane), (uint32_t)rootg);
+        }
+        nreq += __popc(eh);
+        if (eb != 0ull && __builtin_amdgcn_inverse_ballot_w64(eb)) {
+          const int slot = nreq + __popcll((unsigned long long)(eb & ((1ull << lane) - 1ull)));
+          if (MOD_CHECK(a, slot < a.req_cap, 12)) req[slot] = make_uint2((uint32_t)(hgrow + lane), (uint32_t)rootg);
+        }
+        nreq += __popcll((unsigned long long)eb);
+      }
+    }
+    if (single) break;
+    R = andn(R, S);
+  }
+  // ---- tile pixels without any edge: each its own root with an empty key (the reference never labels them) ----
+  {
+    uint64_t todo = __ballot((Za | Zb) != 0u);
+    while (todo) {
+      const int l = __builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      if (__builtin_amdgcn_inverse_ballot_w64(lane_bits(Za, Zb, l))) {
+        const int p = (y0 + l - HL) * W + x0 + lane;
+        a.parent[fN + p] = p; a.rsize[fN + p] = 1; a.rkey[fN + p] = kKeyNone;
+      }
     }
   }
-  if (lane == 0) hdr[1] = nreq;
-#ifdef MOD_PHASE_COUNTERS
-  RSTAMP(15)
-  rc_[0] = 1; rc_[10] = clock64() - rt0_; rc_[11] = nreq;
-  if ((c.debug & 128) && lane == 0)
-    for (int i = 0; i < 16; i++) atomicAdd(&a.dbg[i], rc_[i]);
-#endif
-#undef RCOUNT
-#undef RSTAMP
+  if (il && y0 + lane - HL < H) a.lroot[((size_t)f * H + (y0 + lane - HL)) * MW + wi] = ((uint64_t)rootB << 32) | rootA;
+  if (lane == 0) { hdr[1] = nreq; hdr[0] = 2; }                       // 2: done here (k_ccl_tile_list never sees the tile)
 }
-#undef ROWS_DPP
-}  // namespace rows
+}  // namespace bits
+
 
 // Tile headers from a mask plane that did not come out of the fused scene-flow kernel (mod_cluster_dev): {1, 0} for tiles with a
 // dynamic pixel, {0, 0} for the others.  One thread per tile.
@@ -1913,16 +1771,18 @@ static dim3 tile_grid(const DevCam &c, int frames) { return dim3(c.mask_words, (
 
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 block(64, kTileWaves, 1), tgrid = tile_grid(c, frames);
-  // MOD_TILE_KERNEL=rows selects the one-wave-per-tile kernel (k_ccl_rows, neighbor_distance <= 4): bit-exact, a third of the
-  // instructions, and SLOWER (4.6 vs 2.2 ms per 512 pairs, profiles/r03_tile_kernel_notes.md) — kept as the measured alternative
-  static const bool use_rows = [] { const char *e = std::getenv("MOD_TILE_KERNEL"); return e && std::string(e) == "rows"; }();
-  const dim3 rgrid((tgrid.x + ROWS_TPW - 1) / ROWS_TPW, tgrid.y, tgrid.z);
-  if (c.n == 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<true>, rgrid, dim3(64, ROWS_TPW, 1), 0, s, c, a); return; }
-  if (c.n < 4 && use_rows) { hipLaunchKernelGGL(rows::k_ccl_rows<false>, rgrid, dim3(64, ROWS_TPW, 1), 0, s, c, a); return; }
-  const dim3 ggrid((tgrid.x + CCL_TPB - 1) / CCL_TPB, tgrid.y, tgrid.z);
   const int tx = (int)tgrid.x, tyn = (int)tgrid.y;
-  if (c.n == 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, true>), ggrid, block, 0, s, c, a, tx, tyn);
-  else if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, false>), ggrid, block, 0, s, c, a, tx, tyn);
+  if (c.n == 4) {
+    // the reference's default window: bit-plane kernel first (one wave per tile), then the union-find kernel over the tiles it
+    // listed — resident workgroups (8 per CU) that pull tiles with an atomic cursor
+    const dim3 bgrid((tgrid.x + bits::kTilesPerBlock - 1) / bits::kTilesPerBlock, tgrid.y, tgrid.z);
+    hipLaunchKernelGGL(bits::k_ccl_bits, bgrid, dim3(64, bits::kTilesPerBlock, 1), 0, s, c, a, tx, tyn);
+    const unsigned total = tgrid.x * tgrid.y * tgrid.z;
+    hipLaunchKernelGGL((k_ccl_tile_list<kTileH, 4, kTileWaves, true>), dim3(std::min(2048u, total)), block, 0, s, c, a, tx, tyn);
+    return;
+  }
+  const dim3 ggrid((tgrid.x + CCL_TPB - 1) / CCL_TPB, tgrid.y, tgrid.z);
+  if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile<kTileH, 4, kTileWaves, false>), ggrid, block, 0, s, c, a, tx, tyn);
   else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile<kTileH, 8, kTileWaves, false>), ggrid, block, 0, s, c, a, tx, tyn);
   else hipLaunchKernelGGL((k_ccl_tile<kTileH, 16, kTileWaves, false>), ggrid, block, 0, s, c, a, tx, tyn);
 }

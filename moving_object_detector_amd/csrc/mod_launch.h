@@ -26,7 +26,8 @@ struct ClArgs {
   int32_t *rsize;             // [F][N] member count of the component rooted at this pixel (sparse: only root entries are touched)
   int32_t *rkey;              // [F][N] its first_edge_key; after k_select the new label of a final root, or -1
   ClusterBox *cbox;           // [F][max_objects] bounding boxes of the surviving clusters (k_select init, k_final atomics)
-  int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects, 3 overflow flags
+  int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects; of frame 0 also (counts of the whole launch): 3 cursor into
+                              // `tilelist`, 4 its length, 5 k_median's cursor into `worklist`, 6 its length, 7 length of `tielist`
   ClusterInfo *clusters;      // [F][max_objects]
   uint32_t *mbits;            // [F][N] ||v|| bit patterns of the members, grouped per cluster (SoA with mpix)
   uint32_t *mpix;             // [F][N] pixel index of each member
@@ -39,7 +40,9 @@ struct ClArgs {
   int32_t max_objects;
   int32_t xy_from_z;          // the planes are the fused scene-flow kernel's of this call: x, y of a valid pixel are functions of z
   uint2 *requests;            // [F][tiles][req_cap] cross-tile link requests (halo pixel, tile root)
-  int32_t *tilehdr;           // [F][tiles][2]: the tile has a dynamic pixel (set together with the mask words), number of requests
+  int32_t *tilehdr;           // [F][tiles][2]: 0 no dynamic pixel / 1 has one (set together with the mask words) / 2 done by k_ccl_bits;
+                              // number of requests
+  uint32_t *tilelist;         // [F * tiles] tiles that k_ccl_bits left to the union-find kernel (frame * tiles + tile)
   int32_t req_cap;
   unsigned long long *dbg;    // [32] cycle counters, only touched when DevCam.debug & 128
 };

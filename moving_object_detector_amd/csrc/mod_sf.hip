@@ -35,6 +35,7 @@ struct Buffers {
   unsigned long long *dbg = nullptr;
   uint2 *requests = nullptr;
   int32_t *tilehdr = nullptr;
+  uint32_t *tilelist = nullptr;
   size_t req_alloc = 0;                     // entries currently allocated for `requests`
   // one-frame staging for the *_host entry points (allocated on first use)
   float *h_dnow = nullptr, *h_dprev = nullptr, *h_flow = nullptr, *h_planes = nullptr;
@@ -297,7 +298,7 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   a.objects = out->objects; a.n_objects = out->n_objects;
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
   a.xy_from_z = flags_ready ? 1 : 0;                  // only mod_process_dev's fused path hands over its own scene-flow planes
-  a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
+  a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.tilelist = c->b.tilelist; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
   ClusterInfo *const rank_scratch = c->b.clusters + (size_t)c->cfg.max_frames * c->max_objects;   // second half of the allocation
   {
     StageTimer t(c, MOD_STAGE_CCL_TILE);
@@ -366,6 +367,7 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   {
     const size_t tiles = (size_t)c->max_mask_words * ((cfg->max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
     ok &= dalloc(&c->b.tilehdr, (size_t)F * tiles * 2) == hipSuccess;
+    ok &= dalloc(&c->b.tilelist, (size_t)F * tiles) == hipSuccess;
   }
   ok &= dalloc(&c->b.dbg, 64) == hipSuccess;
   if (ok) ok &= hipMemset(c->b.dbg, 0, 64 * 8) == hipSuccess;
@@ -385,7 +387,7 @@ void mod_destroy(ModContext *c) {
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
   void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.rsize, b.rkey, b.cbox, b.counters, b.clusters, b.mbits, b.mpix,
-                 b.cursors, b.worklist, b.dbg, b.requests, b.tilehdr, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects, b.sgm_census, b.sgm_maps, b.sgm_S};
+                 b.cursors, b.worklist, b.dbg, b.requests, b.tilehdr, b.tilelist, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects, b.sgm_census, b.sgm_maps, b.sgm_S};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
     if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
