@@ -714,7 +714,7 @@ __device__ __forceinline__ uint64_t lane_bits(uint32_t lo, uint32_t hi, int l) {
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, l);
 }
 
-constexpr int kTilesPerBlock = 4;
+constexpr int kTilesPerBlock = 4, kMaxClasses = 4;
 
 __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClArgs a, int tiles_x, int tiles_y) {
   const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
@@ -726,24 +726,41 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
   const int x0 = wi * 64, y0 = ty * TH, MW = c.mask_words, W = c.W, H = c.H;
   const size_t N = (size_t)W * H, fN = (size_t)f * N;
   // ---- the mask words of the 20 grid rows, lane = row -------------------------------------------------------------------------
-  Row3 M;
+  Row3 Mrem;                                                           // dynamic cells that no depth class holds yet
   {
     const int gy = y0 - HL + lane;
     const bool inrow = lane < PH && gy >= 0 && gy < H;
     const uint64_t *mr = a.mask + ((size_t)f * H + (inrow ? gy : 0)) * MW;
     const uint64_t q0 = mr[wi], qL = mr[max(wi - 1, 0)];              // unconditional loads, clamped addresses
-    M.h = (inrow && wi > 0) ? ((uint32_t)(qL >> 32) & 0xF0000000u) : 0u;
-    M.a = inrow ? (uint32_t)q0 : 0u;
-    M.b = inrow ? (uint32_t)(q0 >> 32) : 0u;
+    Mrem.h = (inrow && wi > 0) ? ((uint32_t)(qL >> 32) & 0xF0000000u) : 0u;
+    Mrem.a = inrow ? (uint32_t)q0 : 0u;
+    Mrem.b = inrow ? (uint32_t)(q0 >> 32) : 0u;
   }
-  // ---- can a depth gate fire?  Not when the dynamic cells of the grid span at most depth_diff: |z_p - z_q| <= max - min for every
-  // pair, and F32 subtraction is monotone.  NaN depths link with everything (`!(NaN > th)`) and are left out of the range. -------
+  const bool il = lane >= HL && lane < PH;                             // a tile row
+  const float th = c.depth_th, qnan = __uint_as_float(0x7fc00000u);
+  // (uniform row base + 32-bit lane offset: the `global_load v, v_off, s[base]` form, no 64-bit address arithmetic per lane)
+  const uint32_t oc = 4u * (uint32_t)min(x0 + lane, W - 1), oh = 4u * (uint32_t)max(x0 - HL + min(lane, HL - 1), 0);
+  uint32_t rootA = 0u, rootB = 0u;                                     // root bits of the tile rows (lane = row)
+  int nreq = 0;
+  uint2 *req = a.requests + tix * a.req_cap;
+  float hi_prev = 0.0f;
+  bool bail = false;
+  // ---- depth classes.  comparePoints links two dynamic pixels unless |z_p - z_q| > depth_diff.  Sort the dynamic cells of the grid
+  // by depth in thought: a CLASS is a stretch that spans at most depth_diff (every gate inside it passes: |z_p - z_q| <= max - min,
+  // and F32 subtraction is monotone) and lies more than depth_diff from the next cell on either side (every gate that leaves it
+  // fires).  Then the tile's components are those of each class's MASK, class by class.  Classes are peeled off from the
+  // nearest: lo = smallest depth left, members = cells with !(z - lo > th); the tile goes to the union-find kernel when a class
+  // is not clear of the next one, when more than kMaxClasses are needed, or when a dynamic cell has a NaN depth (NaN links with
+  // everything).  One class — a tile inside one object — is the usual case; object rims have two. --------------------------------
+  // The depths of the grid are read from HBM once: the first sweep (smallest / largest depth of the tile) works on them as they
+  // arrive and parks them in LDS (5.4 KB per wave) for the sweeps of a tile with more than one class.
+  __shared__ float zlds[kTilesPerBlock][PH][64 + HL];
+  float(*zl)[64 + HL] = zlds[wv];
+  const int hcol = 64 + min(lane, HL - 1);                             // lanes 3 .. 63 all hold (and store) the halo column x0 - 1
+  float lo = qnan, hi = qnan;
+  uint64_t nanb = 0ull;
   {
-    const float qnan = __uint_as_float(0x7fc00000u);
-    float zmin = qnan, zmax = qnan;
-    // (uniform row base + 32-bit lane offset: the `global_load v, v_off, s[base]` form, no 64-bit address arithmetic per lane)
-    const uint32_t oc = 4u * (uint32_t)min(x0 + lane, W - 1), oh = 4u * (uint32_t)max(x0 - HL + min(lane, HL - 1), 0);
-    constexpr int HB = PH / 2;                                         // two batches of 10 rows: 20 loads in flight
+    constexpr int HB = PH / 2;                                         // two batches of 10 rows: 20 loads in flight, 20 registers
 #pragma unroll
     for (int g0 = 0; g0 < PH; g0 += HB) {
       float zr[HB], zh[HB];
@@ -757,21 +774,59 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
 #pragma unroll
       for (int i = 0; i < HB; i++) {
         const int gr = g0 + i;
-        const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(M.a, M.b, gr));
-        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)M.h, gr) >> 28));
+        const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
+        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)Mrem.h, gr) >> 28));
         const float z1 = dyn ? zr[i] : qnan, z2 = hdyn ? zh[i] : qnan;
-        zmin = fminf(zmin, fminf(z1, z2));
-        zmax = fmaxf(zmax, fmaxf(z1, z2));
+        lo = fminf(lo, fminf(z1, z2));
+        hi = fmaxf(hi, fmaxf(z1, z2));
+        zl[gr][lane] = zr[i];
+        zl[gr][hcol] = zh[i];
+        // the fused scene-flow kernel never marks a pixel without a finite depth as dynamic; a caller's cloud may
+        if (!a.xy_from_z) nanb |= __ballot((dyn & (zr[i] != zr[i])) | (hdyn & (zh[i] != zh[i])));
       }
     }
-    zmin = wave_fmin(zmin); zmax = wave_fmax(zmax);
-    if (zmax - zmin > c.depth_th) {                                   // wave-uniform: leave the tile to the union-find kernel
-      if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;
-      return;
-    }
   }
+  if (nanb != 0ull) {                                                  // wave-uniform
+    if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;
+    return;
+  }
+  for (int pass = 0;; pass++) {                                        // wave-uniform
+    if (pass == kMaxClasses) { bail = true; break; }
+    if (pass > 0) {                                                    // smallest / largest depth of what is left
+      lo = qnan; hi = qnan;
+#pragma unroll 5
+      for (int gr = 0; gr < PH; gr++) {
+        const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
+        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)Mrem.h, gr) >> 28));
+        const float z1 = dyn ? zl[gr][lane] : qnan, z2 = hdyn ? zl[gr][hcol] : qnan;
+        lo = fminf(lo, fminf(z1, z2));
+        hi = fmaxf(hi, fmaxf(z1, z2));
+      }
+    }
+    lo = wave_fmin(lo); hi = wave_fmax(hi);
+    Row3 M;                                                            // the class
+    if (!(hi - lo > th)) { M = Mrem; Mrem = {0u, 0u, 0u}; }            // everything that is left (wave-uniform)
+    else {
+      M = {0u, 0u, 0u};
+      float chi = qnan;
+#pragma unroll 5
+      for (int gr = 0; gr < PH; gr++) {
+        const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
+        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)Mrem.h, gr) >> 28));
+        const float z1 = zl[gr][lane], z2 = zl[gr][hcol];
+        const bool in1 = dyn & !(z1 - lo > th), in2 = hdyn & !(z2 - lo > th);
+        const uint64_t b1 = __ballot(in1);
+        const uint32_t b2 = (uint32_t)__ballot(in2) << 28;
+        const bool me = lane == gr;                                    // into the row's lane (three selects)
+        M.a = me ? (uint32_t)b1 : M.a; M.b = me ? (uint32_t)(b1 >> 32) : M.b; M.h = me ? b2 : M.h;
+        chi = fmaxf(chi, fmaxf(in1 ? z1 : qnan, in2 ? z2 : qnan));
+      }
+      hi = wave_fmax(chi);
+      Mrem = andn(Mrem, M);
+    }
+    if (pass > 0 && !(lo - hi_prev > th)) { bail = true; break; }      // the class before this one was not clear of it
+    hi_prev = hi;
   // ---- per-row facts ---------------------------------------------------------------------------------------------------------------
-  const bool il = lane >= HL && lane < PH;                             // a tile row
   Row3 drA, drX, dlA, dlX;
   dil_r(M, drA, drX);
   dil_l(M, dlA, dlX);
@@ -786,9 +841,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
   const Row3 rC = rev(C);
   Row3 R = {0u, il ? (M.a & E.a) : 0u, il ? (M.b & E.b) : 0u};         // tile pixels with an edge that no component holds yet
   const uint32_t Za = il ? (M.a & ~E.a) : 0u, Zb = il ? (M.b & ~E.b) : 0u;   // tile pixels without any edge: roots of their own
-  uint32_t rootA = Za, rootB = Zb;
-  int nreq = 0;
-  uint2 *req = a.requests + tix * a.req_cap;
+  rootA |= Za; rootB |= Zb;
   // one component by inspection?  Every non-empty row is ONE closed run whose cells all have an edge, and every non-empty row
   // but the first has a link to a row above: by induction over the rows all dynamic cells of the grid are connected.
   bool single;
@@ -881,6 +934,12 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
         a.parent[fN + p] = p; a.rsize[fN + p] = 1; a.rkey[fN + p] = kKeyNone;
       }
     }
+  }
+    if (__ballot(any(Mrem)) == 0ull) break;                            // wave-uniform: every dynamic cell is in a class
+  }
+  if (bail) {                                                          // wave-uniform: leave the tile to the union-find kernel, which
+    if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;   // rewrites whatever classes published before the bail
+    return;
   }
   if (il && y0 + lane - HL < H) a.lroot[((size_t)f * H + (y0 + lane - HL)) * MW + wi] = ((uint64_t)rootB << 32) | rootA;
   if (lane == 0) { hdr[1] = nreq; hdr[0] = 2; }                       // 2: done here (k_ccl_tile_list never sees the tile)
