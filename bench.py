@@ -20,6 +20,12 @@ import os
 import sys
 import time
 
+# RCCL across processes needs dmabuf IPC on this pool's driver: with the legacy IPC mode hipIpcGetMemHandle fails with "invalid
+# argument" (stated by the GPU pool's environment notes; the launchers export it, an external `torchrun ... bench.py` may not).
+# The HSA runtime reads its environment when it loads, so this has to stand before `import torch` — here, at import of this file.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+IPC_ENV_SET_BEFORE_TORCH = "torch" not in sys.modules and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # numpy / torch are imported inside main(): with --gpus N > 1 this process only starts the N ranks and must not touch the GPU
@@ -57,6 +63,9 @@ def parse():
     ap.add_argument("--no-config5", action="store_true", help="skip the short config-5 leg (on-GPU SGM disparity, outside `value`)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + config broadcast + stream sharding only, no GPU work (exercises the N-rank launch path on a CPU box)")
+    ap.add_argument("--fail-rank", type=int, default=None,
+                    help="rehearsal of a rank failure: this rank raises after the rendezvous (the job must exit non-zero, name the rank on "
+                         "stderr and print no JSON line)")
     return ap.parse_args()
 
 
@@ -94,8 +103,8 @@ def cpu_baseline(cam, prm, batch, n_sample, sgm=None):
                     refs.append((ref, lab, objs))
         m = n * passes[mode]
         res[mode] = {"scene_flow_ms": 1e3 * sf / m, "cluster_ms": 1e3 * cl / m, "pairs_per_s": m / (sf + cl)}
-    cores = os.cpu_count() or 1
-    workers = max(1, min(cores, 64))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, cores)                            # every core this process may run on
     reps = max(n, 4 * workers)
     t0 = time.perf_counter()
     with ThreadPoolExecutor(workers) as ex:
@@ -196,6 +205,22 @@ def config5_leg(dev, local_rank):
 
 
 def main():
+    """Rank-level failures are fatal and visible: one line on stderr that names the rank, a non-zero exit code (the launcher then
+    stops the other ranks and fails too), and no JSON line — the line is written last, by rank 0, after every rank's timed work."""
+    rank = os.environ.get("RANK", "0")
+    try:
+        run()
+    except SystemExit:
+        raise
+    except BaseException as e:                               # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        sys.stderr.write(f"bench.py: rank {rank} failed: {type(e).__name__}: {e}\n")
+        sys.stderr.flush()
+        os._exit(1)                                          # not sys.exit: a hung communicator must not keep the process in its destructors
+
+
+def run():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and (args.gpus or 1) > 1:
@@ -259,14 +284,19 @@ def main():
 
     total = world * G                                   # distinct frames of the whole job's stream
     lo, hi = mdist.shard_range(total, rank, world)
+    if args.fail_rank is not None and rank == args.fail_rank:
+        raise RuntimeError("rehearsed failure (--fail-rank)")
     if args.launch_check:
         counts = mdist.gather_counts(torch.tensor([lo, hi], dtype=torch.int32))
-        if rank == 0:
-            emit({"launch_check": True, "n_gpus": world, "backend": "gloo", "camera_width": cam_s.width,
-                              "cluster_size": prm_s.cluster_size, "shards": [c.tolist() for c in counts]})
-        if group_up:
+        if group_up:                                      # as in the real run: the group goes down before rank 0 works alone
             dist.barrier()
             dist.destroy_process_group()
+        if rank == 0:
+            emit({"launch_check": True, "n_gpus": world, "backend": "gloo", "camera_width": cam_s.width,
+                              "cluster_size": prm_s.cluster_size, "shards": [c.tolist() for c in counts],
+                              "ipc_env_set_before_torch": IPC_ENV_SET_BEFORE_TORCH,
+                              "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                              "group_down_before_solo_legs": not dist.is_initialized()})
         return
 
     from moving_object_detector_amd.pipeline import PLANES, Context
@@ -324,6 +354,13 @@ def main():
     stage = [ctx.stage_time(i) for i in range(capi.MOD_STAGE_COUNT)]
     ctx.set_profiling(False)
     elapsed = mdist.max_over_ranks(elapsed, device=dev if on_dev else None)     # the slowest rank's time (device all-reduce on RCCL)
+    # The job's collective work ends here: the group goes down on every rank BEFORE rank 0's solo legs (config 5, ~15 s of CPU
+    # baseline), so that no rank sits in an RCCL barrier with a watchdog running while rank 0 computes alone.
+    coll = {"executed": bool(group_up), "backend": (dist.get_backend() if group_up else None),
+            "world_size": (dist.get_world_size() if group_up else 0)}
+    if group_up:
+        dist.barrier()
+        dist.destroy_process_group()
 
     if rank == 0:
         N = W * H
@@ -408,9 +445,9 @@ def main():
                                   else "independent synthetic pairs per rank"),
                        "sharding": f"frames x{world}",
                        "collective": ("one broadcast of the intrinsics/params block before the timed region + one all-reduce (MAX) of the elapsed time"
-                                      if group_up else "none: no process group in this run"),
-                       "collective_executed": bool(group_up), "collective_backend": (dist.get_backend() if group_up else None),
-                       "collective_on_device": bool(group_up and on_dev), "collective_world_size": (dist.get_world_size() if group_up else 0),
+                                      if coll["executed"] else "none: no process group in this run"),
+                       "collective_executed": coll["executed"], "collective_backend": coll["backend"],
+                       "collective_on_device": bool(coll["executed"] and on_dev), "collective_world_size": coll["world_size"],
                        "collective_error": group_error},
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -418,9 +455,6 @@ def main():
             line["config5"] = c5
         emit(line)
     ctx.close()
-    if group_up:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

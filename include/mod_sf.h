@@ -218,7 +218,10 @@ int  mod_sgm_path_dev(ModContext *ctx, int32_t frames, const uint32_t *census_le
 
 /* ---- host-pointer convenience (what a ROS node with host-side messages calls) ----------------------------- */
 /* One frame, host buffers in/out; any output pointer may be NULL.  Returns a skip code exactly where construct()
- * would publish nothing.  cloud_aos: W*H*32 bytes; labels: W*H int32; objects: capacity `max_objects`. */
+ * would publish nothing.  cloud_aos: W*H*32 bytes; labels: W*H int32; objects: capacity `max_objects`.
+ * With labels == NULL and objects == NULL the clustering stage does not run at all (the reference's constructor node does not
+ * cluster; its clusterer runs whenever a cloud arrives, clusterer_nodelet.cpp:231): a node that serves ~scene_flow alone pays for
+ * the scene-flow stage only.  The same holds for mod_submit_frame_host and mod_submit_stereo_host. */
 int  mod_process_frame_host(ModContext *ctx,
                             const float *disparity_now, const float *disparity_prev, const float *flow,
                             const ModTransform *transform, double dt,

@@ -17,13 +17,15 @@
 
 // Index assertions of the diagnostic build `make CHECKED=1` (libmod_sf_checked.so, tests/test_gpu_checked_build.py): every index
 // the cluster kernels derive from DATA IN MEMORY (parent entries, link requests, member slots, cluster tables) is checked
-// before it is used; a violation is counted in ClArgs.dbg[48 + code] and the access is skipped instead of faulting the GPU.
+// before it is used; a violation is counted in ClArgs.dbg[kDbgCheckBase + code] and the access is skipped instead of faulting the GPU.
 // A product build compiles the conditions away.  Codes: 0 link request pixel, 1 link roots, 2 merge root, 3 root list slot,
 // 4 select root, 5 final: parent entry, 6 final: tile-root cell, 7 final: label, 8 final: member slot, 9 median: segment,
-// 10 median: member pixel, 11 ties: member slot, 12 scene flow: a late kernarg load disagrees with the argument it stands for, 13 tile: root pixel, 14 ties: members placed != cluster size,
-// 15 select: more clusters than max_objects.
+// 10 median: member pixel, 11 ties: member slot, 12 tile: link-request slot, 13 tile: root pixel, 14 ties: members placed != cluster size,
+// 15 select: more clusters than max_objects, 16 scene flow: a late kernarg load disagrees with the argument it stands for.
+// dbg layout: [0, 64) cycle counters of the PHASE_COUNTERS build, [64, 96) one counter per code.
+constexpr int kDbgCheckBase = 64, kDbgWords = 96;
 #ifdef MOD_CHECKED
-#define MOD_CHECK(a, cond, code) ((cond) ? true : (atomicAdd(&(a).dbg[48 + (code)], 1ull), false))
+#define MOD_CHECK(a, cond, code) ((cond) ? true : (atomicAdd(&(a).dbg[kDbgCheckBase + (code)], 1ull), false))
 #else
 #define MOD_CHECK(a, cond, code) true
 #endif

@@ -12,7 +12,7 @@ struct SfArgs {
   const FrameConst *fc;               // [F] device
   int32_t *tilehdr;                   // [F][tiles][2] or null: header word 0 of every cluster tile with a dynamic pixel is set to 1
   int32_t tile_rows, tiles_x, tiles_per_frame;   // (zeroed by the caller beforehand); tile = 64 x tile_rows pixels
-  unsigned long long *dbg;            // the context's diagnostic counters (checked build: index assertion 12), unused by a product build
+  unsigned long long *dbg;            // the context's diagnostic counters (checked build: index assertion 16), unused by a product build
 };
 
 // Scratch the clustering kernels work in; all device pointers, sized by the context.
@@ -44,7 +44,7 @@ struct ClArgs {
                               // number of requests
   uint32_t *tilelist;         // [F * tiles] tiles that k_ccl_bits left to the union-find kernel (frame * tiles + tile)
   int32_t req_cap;
-  unsigned long long *dbg;    // [32] cycle counters, only touched when DevCam.debug & 128
+  unsigned long long *dbg;    // [96] diagnostic counters (mod_device.h): cycle counters when DevCam.debug & 128, index assertions of the checked build
 };
 
 void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s);

@@ -86,6 +86,10 @@ struct ModContext {
     hipEvent_t ev_img[MOD_PIPELINE_DEPTH] = {};    // ... the estimator has been enqueued behind them (context stream)
     bool img_used[MOD_PIPELINE_DEPTH] = {};
     hipEvent_t ev_ring = nullptr;                  // last disparity plane written by kernels (stereo path)
+    // a ring plane may still be on its way to a caller's `disparity` buffer (result stream) when a frame that ended at a guard —
+    // it takes a plane but no ticket — has advanced the ring back to it: the plane's next writer waits for that copy
+    hipEvent_t ev_plane_read[MOD_PIPELINE_DEPTH + 1] = {};
+    bool plane_read_pending[MOD_PIPELINE_DEPTH + 1] = {};
     bool ring_by_kernels = false;
     int64_t dring = 0;                             // disparity planes handed out so far: plane of the next frame = dring % (DEPTH + 1)
     int64_t seq = 0;                               // frames submitted so far
@@ -369,8 +373,8 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
     ok &= dalloc(&c->b.tilehdr, (size_t)F * tiles * 2) == hipSuccess;
     ok &= dalloc(&c->b.tilelist, (size_t)F * tiles) == hipSuccess;
   }
-  ok &= dalloc(&c->b.dbg, 64) == hipSuccess;
-  if (ok) ok &= hipMemset(c->b.dbg, 0, 64 * 8) == hipSuccess;
+  ok &= dalloc(&c->b.dbg, kDbgWords) == hipSuccess;
+  if (ok) ok &= hipMemset(c->b.dbg, 0, kDbgWords * 8) == hipSuccess;
   if (ok) ok &= hipMemset((char *)c->b.dbg + 42 * 8, 0xFF, 8) == hipSuccess;   // slot 42 is a minimum
   for (int i = 0; i < kRing && ok; i++) {
     ok &= hipHostMalloc((void **)&c->pinned[i], sizeof(FrameConst) * F, hipHostMallocDefault) == hipSuccess;
@@ -409,6 +413,7 @@ void mod_destroy(ModContext *c) {
       for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     }
     if (p.ev_ring) (void)hipEventDestroy(p.ev_ring);
+    for (hipEvent_t e : p.ev_plane_read) if (e) (void)hipEventDestroy(e);
   }
   for (hipStream_t q : c->b.sgm_side) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
   for (int k = 0; k < 2; k++) {
@@ -581,16 +586,19 @@ int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left,
   // (stage entry point, tests and tracing) the D == 128 kernels read up to 127 words before the right plane: give them a padded copy
   const size_t words = (size_t)frames * c->dc.W * c->dc.H;
   uint32_t *padded = nullptr;
+  hipError_t e = hipSuccess;
   if (p->disparities == 128) {
-    HIP_TRY(c, hipMalloc((void **)&padded, (words + 128) * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemsetAsync(padded, 0, 128 * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipMemcpyAsync(padded + 128, census_right, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    e = hipMalloc((void **)&padded, (words + 128) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(padded, 0, 128 * sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(padded + 128, census_right, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream);
   }
-  launch_sgm_path(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction, census_left, padded ? padded + 128 : census_right, path_cost,
-                  matching_cost, padded != nullptr, c->stream);
-  const hipError_t le = hipGetLastError();
-  if (padded) { (void)hipStreamSynchronize(c->stream); (void)hipFree(padded); }
-  HIP_TRY(c, le);
+  if (e == hipSuccess) {
+    launch_sgm_path(c->dc.W, c->dc.H, frames, p->disparities, p->p1, p->p2, direction, census_left, padded ? padded + 128 : census_right, path_cost,
+                    matching_cost, padded != nullptr, c->stream);
+    e = hipGetLastError();
+  }
+  if (padded) { (void)hipStreamSynchronize(c->stream); (void)hipFree(padded); }   // on every path, the failed ones included
+  HIP_TRY(c, e);
   return MOD_OK;
 }
 
@@ -599,7 +607,7 @@ int mod_sgm_path_dev(ModContext *c, int32_t frames, const uint32_t *census_left,
 // back by the path kernels: a running sum would put its load latency into every step of a path), four disparity maps.  Census
 // planes and volumes exist twice: consecutive groups overlap (mod_sgm_compute_dev).
 constexpr int kSgmPaths = 8;
-static const int kSgmGroup = [] { const char *e = getenv("MOD_SGM_GROUP"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 64 ? v : 8; }();   // frames per group (experiment knob)
+constexpr int kSgmGroup = 8;                             // frames per group (4 .. 16 measured in round 3: 8 is the knee)
 constexpr size_t kSgmVolumeBudget = (size_t)24 << 30;    // bytes of cost volumes a context may hold
 
 static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
@@ -614,23 +622,9 @@ static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
       HIP_TRY(c, hipEventCreateWithFlags(&b.sgm_fork[k], hipEventDisableTiming));
       for (int i = 0; i < 8; i++) HIP_TRY(c, hipEventCreateWithFlags(&b.sgm_join[k][i], hipEventDisableTiming));
     }
-    // The path grid occupies every wave slot of the CUs it may use for milliseconds (a row's wave walks 1280 steps); the
-    // winner-take-all of the group before it, an HBM-bound kernel on the context's stream, would only get slots as path waves
-    // retire.  The path stream therefore leaves one CU in every `keep` free (MOD_SGM_CU_KEEP, default 8; 0 = no mask).
-    {
-      static const int keep = [] { const char *e = getenv("MOD_SGM_CU_KEEP"); const int v = e ? atoi(e) : 8; return v >= 0 && v <= 64 ? v : 8; }();
-      hipDeviceProp_t prop;
-      HIP_TRY(c, hipGetDeviceProperties(&prop, c->cfg.device));
-      const int ncu = prop.multiProcessorCount;
-      if (keep >= 2 && ncu >= 2 * keep) {
-        std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-        for (int i = 0; i < ncu; i++) if (i % keep != keep - 1) mask[i / 32] |= 1u << (i % 32);
-        HIP_TRY(c, hipExtStreamCreateWithCUMask(&b.sgm_side[0], (uint32_t)mask.size(), mask.data()));
-      } else {
-        HIP_TRY(c, hipStreamCreateWithFlags(&b.sgm_side[0], hipStreamNonBlocking));
-      }
-    }
-    for (int i = 1; i < 8; i++) HIP_TRY(c, hipStreamCreateWithFlags(&b.sgm_side[i], hipStreamNonBlocking));
+    // (a CU-masked path stream that kept one CU in 8 / 4 / 3 free for the winner-take-all of the group before was measured in
+    // round 3 and changed nothing: plain non-blocking side streams)
+    for (int i = 0; i < 8; i++) HIP_TRY(c, hipStreamCreateWithFlags(&b.sgm_side[i], hipStreamNonBlocking));
   }
   if (b.sgm_S && b.sgm_D >= D && b.sgm_G >= g) return MOD_OK;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -640,7 +634,9 @@ static int ensure_sgm_scratch(ModContext *c, int D, int frames, int *group) {
   void *old[] = {b.sgm_S, b.sgm_census, b.sgm_maps};
   for (void *q : old) if (q) HIP_TRY(c, hipFree(q));
   b.sgm_S = nullptr; b.sgm_census = nullptr; b.sgm_maps = nullptr; b.sgm_D = 0; b.sgm_G = 0;
-  HIP_TRY(c, dalloc(&b.sgm_census, 2 * 2 * N * g2));                       // two sets: see mod_sgm_compute_dev
+  // two sets (see mod_sgm_compute_dev) behind 128 words of lead: the D == 128 path kernels read up to 127 words to the left of a
+  // right census plane unconditionally (discarded: disparities that do not exist) — inside the allocation even for tiny images
+  HIP_TRY(c, dalloc(&b.sgm_census, 2 * 2 * N * g2 + 128));
   HIP_TRY(c, dalloc(&b.sgm_maps, 4 * N * g2));
   HIP_TRY(c, dalloc(&b.sgm_S, 2 * N * (size_t)D2 * g2 * kSgmPaths));
   b.sgm_D = D2; b.sgm_G = g2;
@@ -669,7 +665,7 @@ int mod_sgm_compute_dev(ModContext *c, int32_t frames, const uint8_t *left, cons
   bool all_in_one[2] = {false, false};
   auto start = [&](int k) -> int {
     const int f0 = k * group, g = std::min(group, frames - f0), s = k & 1;
-    uint32_t *cl = b.sgm_census + s * set_census, *cr = cl + N * g;
+    uint32_t *cl = b.sgm_census + 128 + s * set_census, *cr = cl + N * g;
     launch_sgm_census(W, H, g, left + (size_t)f0 * N, cl, c->stream);
     launch_sgm_census(W, H, g, right + (size_t)f0 * N, cr, c->stream);
     HIP_TRY(c, hipEventRecord(b.sgm_fork[s], c->stream));
@@ -789,9 +785,13 @@ int mod_process_frame_host(ModContext *c, const float *disparity_now, const floa
   pl.cloud_aos = cloud_aos ? b.h_aos : nullptr;
   ModClusterOut out{};
   out.labels = labels ? b.h_labels : nullptr; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
-  rc = mod_process_dev(c, &in, &pl, &out);
+  // no cluster output asked for (neither labels nor objects): the scene-flow stage alone — a constructor whose moving objects
+  // nobody takes does not cluster (the reference's constructor never does; its clusterer is a node of its own)
+  const bool cluster = labels || objects;
+  rc = cluster ? mod_process_dev(c, &in, &pl, &out) : mod_scene_flow_dev(c, &in, &pl);
   if (rc) return rc;
   if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, b.h_aos, 32 * N, hipMemcpyDeviceToHost, c->stream));
+  if (!cluster) { HIP_TRY(c, hipStreamSynchronize(c->stream)); return MOD_OK; }
   return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
 }
 
@@ -898,6 +898,7 @@ static int ensure_pipe(ModContext *c) {
     if (!p.ev_img[i]) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_img[i], hipEventDisableTiming));
   }
   if (!p.ev_ring) HIP_TRY(c, hipEventCreateWithFlags(&p.ev_ring, hipEventDisableTiming));
+  for (hipEvent_t &e : p.ev_plane_read) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   p.ready = true;
   return MOD_OK;
 }
@@ -924,6 +925,7 @@ int mod_submit_frame_host(ModContext *c, const float *disparity_now, const float
   // at most MOD_PIPELINE_DEPTH - 1 frames are in flight at this point.  (Planes the stereo entry filled were written by kernels,
   // and a frame it skipped took a plane without a ticket: the copy then also waits for the last of those kernels.)
   if (p.ring_by_kernels) { HIP_TRY(c, hipStreamWaitEvent(p.h2d, p.ev_ring, 0)); p.ring_by_kernels = false; }
+  if (p.plane_read_pending[nowi]) { HIP_TRY(c, hipStreamWaitEvent(p.h2d, p.ev_plane_read[nowi], 0)); p.plane_read_pending[nowi] = false; }
   HIP_TRY(c, hipMemcpyAsync(p.dnow[nowi], disparity_now, 4 * N, hipMemcpyHostToDevice, p.h2d));
   if (disparity_prev) HIP_TRY(c, hipMemcpyAsync(p.dprev[slot], disparity_prev, 4 * N, hipMemcpyHostToDevice, p.h2d));
   HIP_TRY(c, hipMemcpyAsync(p.flow[slot], flow, 8 * N, hipMemcpyHostToDevice, p.h2d));
@@ -940,11 +942,13 @@ int mod_submit_frame_host(ModContext *c, const float *disparity_now, const float
   pl.cloud_aos = cloud_aos ? p.aos[slot] : nullptr;
   ModClusterOut out{};
   out.labels = labels ? p.labels[slot] : nullptr; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
-  if ((rc = mod_process_dev(c, &in, &pl, &out))) return rc;
+  const bool cluster = labels || objects;     // neither asked for: the scene-flow stage alone (see mod_process_frame_host)
+  if ((rc = cluster ? mod_process_dev(c, &in, &pl, &out) : mod_scene_flow_dev(c, &in, &pl))) return rc;
   HIP_TRY(c, hipEventRecord(p.ev_done[slot], c->stream));
   // results: their own stream
   HIP_TRY(c, hipStreamWaitEvent(p.d2h, p.ev_done[slot], 0));
-  HIP_TRY(c, hipMemcpyAsync(p.h_n[slot], p.nobj[slot], sizeof(int32_t), hipMemcpyDeviceToHost, p.d2h));
+  if (cluster) HIP_TRY(c, hipMemcpyAsync(p.h_n[slot], p.nobj[slot], sizeof(int32_t), hipMemcpyDeviceToHost, p.d2h));
+  else *p.h_n[slot] = 0;
   if (labels) HIP_TRY(c, hipMemcpyAsync(labels, p.labels[slot], sizeof(int32_t) * N, hipMemcpyDeviceToHost, p.d2h));
   // the count is not known yet: the caller's capacity goes to a pinned staging array (a pageable destination would make this
   // call wait for the kernels); mod_collect_frame_host hands the objects over
@@ -987,6 +991,7 @@ int mod_submit_stereo_host(ModContext *c, const uint8_t *left, const uint8_t *ri
   HIP_TRY(c, hipStreamWaitEvent(c->stream, p.ev_in[slot], 0));
   // estimateDisparity (:258-279) on the GPU, straight into the ring: this plane is `now` here and `previous` of the next frame.
   // Kernels of older frames that read the plane being replaced are ahead of the estimator on the same stream.
+  if (p.plane_read_pending[nowi]) { HIP_TRY(c, hipStreamWaitEvent(c->stream, p.ev_plane_read[nowi], 0)); p.plane_read_pending[nowi] = false; }
   if ((rc = mod_sgm_compute_dev(c, 1, p.img[slot], p.img[slot] + N, sgm, p.dnow[nowi]))) return rc;
   HIP_TRY(c, hipEventRecord(p.ev_img[slot], c->stream));
   HIP_TRY(c, hipEventRecord(p.ev_ring, c->stream));
@@ -1007,12 +1012,18 @@ int mod_submit_stereo_host(ModContext *c, const uint8_t *left, const uint8_t *ri
   pl.cloud_aos = cloud_aos ? p.aos[slot] : nullptr;
   ModClusterOut out{};
   out.labels = labels ? p.labels[slot] : nullptr; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
-  if ((rc = mod_process_dev(c, &in, &pl, &out))) return rc;
+  const bool cluster = labels || objects;     // neither asked for: the scene-flow stage alone (see mod_process_frame_host)
+  if ((rc = cluster ? mod_process_dev(c, &in, &pl, &out) : mod_scene_flow_dev(c, &in, &pl))) return rc;
   HIP_TRY(c, hipEventRecord(p.ev_done[slot], c->stream));
   HIP_TRY(c, hipStreamWaitEvent(p.d2h, p.ev_done[slot], 0));
-  HIP_TRY(c, hipMemcpyAsync(p.h_n[slot], p.nobj[slot], sizeof(int32_t), hipMemcpyDeviceToHost, p.d2h));
+  if (cluster) HIP_TRY(c, hipMemcpyAsync(p.h_n[slot], p.nobj[slot], sizeof(int32_t), hipMemcpyDeviceToHost, p.d2h));
+  else *p.h_n[slot] = 0;
   if (labels) HIP_TRY(c, hipMemcpyAsync(labels, p.labels[slot], sizeof(int32_t) * N, hipMemcpyDeviceToHost, p.d2h));
-  if (disparity) HIP_TRY(c, hipMemcpyAsync(disparity, p.dnow[nowi], sizeof(float) * N, hipMemcpyDeviceToHost, p.d2h));
+  if (disparity) {
+    HIP_TRY(c, hipMemcpyAsync(disparity, p.dnow[nowi], sizeof(float) * N, hipMemcpyDeviceToHost, p.d2h));
+    HIP_TRY(c, hipEventRecord(p.ev_plane_read[nowi], p.d2h));
+    p.plane_read_pending[nowi] = true;
+  }
   const int32_t ncopy = objects ? std::max(0, std::min(max_objects, (int32_t)c->max_objects)) : 0;
   if (ncopy > 0) HIP_TRY(c, hipMemcpyAsync(p.h_obj[slot], p.objects[slot], sizeof(ModObject) * ncopy, hipMemcpyDeviceToHost, p.d2h));
   p.user_obj[slot] = objects; p.user_cap[slot] = ncopy;
@@ -1096,8 +1107,8 @@ int mod_debug_read(ModContext *c, int which, void *dst, unsigned long long bytes
 int mod_debug_counters(ModContext *c, unsigned long long *out32) {
   if (!c || !out32) return MOD_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(out32, c->b.dbg, 64 * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemset(c->b.dbg, 0, 64 * 8));
+  HIP_TRY(c, hipMemcpy(out32, c->b.dbg, kDbgWords * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemset(c->b.dbg, 0, kDbgWords * 8));
   HIP_TRY(c, hipMemset((char *)c->b.dbg + 42 * 8, 0xFF, 8));
   return MOD_OK;
 }

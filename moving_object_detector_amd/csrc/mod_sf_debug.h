@@ -1,6 +1,6 @@
 // mod_sf_debug.h — diagnostic entry points of libmod_sf.so.  NOT part of the product ABI (include/mod_sf.h): they exist only in
 // builds made with `make PHASE_COUNTERS=1`, `make ABLATE=1` (tools/dbg_*.py, tools/ablate.sh; they also read MOD_DEBUG) or
-// `make CHECKED=1` (index assertions, mod_device.h MOD_CHECK: counters 48..63 of mod_debug_counters).
+// `make CHECKED=1` (index assertions, mod_device.h MOD_CHECK: counters 64..95 of mod_debug_counters; the export copies all 96 words).
 #pragma once
 #if defined(MOD_PHASE_COUNTERS) || defined(MOD_ABLATION) || defined(MOD_CHECKED)
 #include "../../include/mod_sf.h"

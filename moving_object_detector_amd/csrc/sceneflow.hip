@@ -131,19 +131,10 @@ __device__ __forceinline__ void sf_stage2a(const DevCam &c, const FrameConst &fc
   // cloud (!isValid); a NaN x passes through the transform untouched -> invalid
   const bool ok = st.go & disp_in_range(c, dpw) & !is_nan_inf_or_negative(dpw) & !(dpw == 0.0f) & !isnan(Xp);
   // ---- residual test (scene_flow_constructor.cpp:196-198): sqrtf(acc) >= flow_th  <=>  acc >= flow_th_sq (host-derived) ----
-#ifdef SF_PACKED_F32   // experiment build: the residual's two lanes as one packed pair (v_pk_add_f32 / v_pk_mul_f32); same roundings
-  typedef float sf_f2 __attribute__((ext_vector_type(2)));
-  const sf_f2 fl = {st.f0, st.f1}, sf = {o.s0, o.s1};
-  const sf_f2 rr = fl - sf, sq = rr * rr;
-  float acc = 0.0f;
-  acc = acc + sq.x;
-  acc = acc + sq.y;
-#else
   const float r0 = st.f0 - o.s0, r1 = st.f1 - o.s1;
   float acc = 0.0f;
   acc = acc + r0 * r0;
   acc = acc + r1 * r1;
-#endif
   const bool moving = acc >= c.flow_th_sq;
   const float safe = (float)fc.pad[0];
   const bool settled = ok & !moving & (fabsf(Xp) <= safe) & (fabsf(Yp) <= safe) & (fabsf(zp) <= safe);
@@ -209,20 +200,10 @@ template <class T> __device__ __forceinline__ void st(void *base, uint32_t byte_
 // arithmetic: with them the kernel wants more than the 102 SGPRs a wave has and spills into VGPR lanes (v_writelane / v_readlane
 // pairs, which take VALU issue slots of a VALU-co-limited kernel).  Read through the kernarg segment pointer: taking the address of
 // a by-value parameter would make the compiler copy it to scratch.
-// Plane stores: SF_NT_PLANES is a bit mask (1 x, 2 y, 4 z, 8 vx, 16 vy, 32 vz) of the planes written with streaming (non-temporal)
-// stores — an experiment knob: means of six alternating runs on one box were 3.649 ms (0), 3.642 (x, y), 3.611 (all six), inside
-// the +-4 % a process varies by (profiles/README.md round 3).  Default 0: plain stores.
-#ifndef SF_NT_PLANES
-#define SF_NT_PLANES 0
-#endif
-template <int BIT> __device__ __forceinline__ void st_plane(float *base, uint32_t byte_off, float a0, float a1, float a2, float a3) {
-  if (SF_NT_PLANES & BIT) {
-    typedef float sf_w4 __attribute__((ext_vector_type(4)));
-    const sf_w4 v = {a0, a1, a2, a3};
-    __builtin_nontemporal_store(v, (sf_w4 *)((char *)base + byte_off));
-  } else {
-    st(base, byte_off, make_float4(a0, a1, a2, a3));
-  }
+// Plane stores are plain stores (streaming stores per plane were measured: no effect beyond the process-to-process spread,
+// profiles/README.md round 3).
+__device__ __forceinline__ void st_plane(float *base, uint32_t byte_off, float a0, float a1, float a2, float a3) {
+  st(base, byte_off, make_float4(a0, a1, a2, a3));
 }
 #define SF_K4 __attribute__((address_space(4)))
 template <class T> __device__ __forceinline__ T karg(size_t off) {
@@ -234,7 +215,7 @@ constexpr size_t kSfArgsAt = (sizeof(DevCam) + alignof(SfArgs) - 1) / alignof(Sf
 // karg()/LATE_A are tied to the signature `k_scene_flow_v4(DevCam c, SfArgs a)`: by-value aggregates are laid out in the kernarg
 // segment in declaration order at their natural alignment (code object v5: explicit arguments first, hidden ones after), i.e.
 // exactly like the members of the struct below.  A change of the signature or of either struct must change this too — a wrong
-// offset would store through garbage pointers.  The checked build also compares LATE_A(vx) with a.vx at run time (code 12).
+// offset would store through garbage pointers.  The checked build also compares LATE_A(vx) with a.vx at run time (code 16).
 struct SfKernargLayout { DevCam c; SfArgs a; };
 static_assert(std::is_trivially_copyable<DevCam>::value && std::is_trivially_copyable<SfArgs>::value, "kernarg structs are copied bytewise");
 static_assert(alignof(DevCam) <= 8 && alignof(SfArgs) <= 8, "kernarg segment is 8-byte aligned per argument here");
@@ -271,15 +252,8 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     const float *dprev_f = a.dprev + fN;
     const float4 dn = ld<float4>(a.dnow + fN, o4);
     const float4 dp = ld<float4>(dprev_f, o4);
-#ifdef SF_NT_FLOW   // experiment: the flow field is read exactly once
-    typedef float sf_v4 __attribute__((ext_vector_type(4)));
-    const sf_v4 fa_ = __builtin_nontemporal_load((const sf_v4 *)((const char *)(a.flow + 2 * fN) + o8));
-    const sf_v4 fb_ = __builtin_nontemporal_load((const sf_v4 *)((const char *)(a.flow + 2 * fN) + o8 + 16u));
-    const float4 fa = make_float4(fa_.x, fa_.y, fa_.z, fa_.w), fb = make_float4(fb_.x, fb_.y, fb_.z, fb_.w);
-#else
     const float4 fa = ld<float4>(a.flow + 2 * fN, o8);
     const float4 fb = ld<float4>(a.flow + 2 * fN, o8 + 16u);
-#endif
     const double ry = c.rayy[y];
     const double2 rxa = ld<double2>(c.rayx, (uint32_t)x0 * 8u);
     const double2 rxb = ld<double2>(c.rayx, (uint32_t)x0 * 8u + 16u);
@@ -290,18 +264,15 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     sf_stage1(c, fc, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2, s2);
     sf_stage1(c, fc, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3, s3);
     // x, y, z are final after stage 1: their stores leave before the gathers come back
-    // (SF_LATE_XYZ, an experiment build: all six plane stores in one clause at the end — profiles/README.md round 3)
-#ifndef SF_LATE_XYZ
-    st_plane<1>(a.x + fN, o4, p0.x, p1.x, p2.x, p3.x);
-    st_plane<2>(a.y + fN, o4, p0.y, p1.y, p2.y, p3.y);
-    st_plane<4>(a.z + fN, o4, p0.z, p1.z, p2.z, p3.z);
-#endif
+    st_plane(a.x + fN, o4, p0.x, p1.x, p2.x, p3.x);
+    st_plane(a.y + fN, o4, p0.y, p1.y, p2.y, p3.y);
+    st_plane(a.z + fN, o4, p0.z, p1.z, p2.z, p3.z);
     // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets; so do the scalar
     // loads of the output pointers that are needed from here on
     float *const out_vx = LATE_A(vx), *const out_vy = LATE_A(vy), *const out_vz = LATE_A(vz);
 #ifdef MOD_CHECKED
     if (out_vx != a.vx || LATE_A(tilehdr) != a.tilehdr || LATE_A(tiles_x) != a.tiles_x) {   // the late loads read what the signature passes
-      if (a.dbg) atomicAdd(&a.dbg[48 + 12], 1ull);
+      if (a.dbg) atomicAdd(&a.dbg[kDbgCheckBase + 16], 1ull);
       return;
     }
 #endif
@@ -328,14 +299,9 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
       sf_stage2b(c, fc, s2, w2, p2);
       sf_stage2b(c, fc, s3, w3, p3);
     }
-#ifdef SF_LATE_XYZ
-    st_plane<1>(a.x + fN, o4, p0.x, p1.x, p2.x, p3.x);
-    st_plane<2>(a.y + fN, o4, p0.y, p1.y, p2.y, p3.y);
-    st_plane<4>(a.z + fN, o4, p0.z, p1.z, p2.z, p3.z);
-#endif
-    st_plane<8>(out_vx + fN, o4, p0.vx, p1.vx, p2.vx, p3.vx);
-    st_plane<16>(out_vy + fN, o4, p0.vy, p1.vy, p2.vy, p3.vy);
-    st_plane<32>(out_vz + fN, o4, p0.vz, p1.vz, p2.vz, p3.vz);
+    st_plane(out_vx + fN, o4, p0.vx, p1.vx, p2.vx, p3.vx);
+    st_plane(out_vy + fN, o4, p0.vy, p1.vy, p2.vy, p3.vy);
+    st_plane(out_vz + fN, o4, p0.vz, p1.vz, p2.vz, p3.vz);
     if (out_aos) {   // pcl::PointXYZVelocity records, 32 B each (pads written as 0)
       float4 *q = out_aos + 2 * fN;
       const uint32_t o32 = pix * 32u;
@@ -362,101 +328,6 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   }
 }
 
-#ifdef SF_8PX
-// Experiment build (profiles/README.md round 3): 8 pixels per thread — two groups of 4 consecutive pixels 256 pixels apart, so that
-// every wave-level load / store stays one contiguous kilobyte; FrameConst, the row's ray, the address setup and the epilogue are
-// paid once per 8 pixels.  Same stage functions, same results.
-__global__ __launch_bounds__(256) void k_scene_flow_v8(DevCam c, SfArgs a) {
-  const int lane = threadIdx.x;
-  uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  {
-    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
-    if ((total & 7u) == 0u) {
-      const uint32_t lin = bx + gridDim.x * (by + gridDim.y * bz);
-      const uint32_t m = (lin & 7u) * (total >> 3) + (lin >> 3);
-      bx = m % gridDim.x;
-      const uint32_t t = m / gridDim.x;
-      by = t % gridDim.y; bz = t / gridDim.y;
-    }
-  }
-  const int y = by * 4 + threadIdx.y;
-  const int f = bz;
-  const size_t fN = (size_t)f * ((size_t)c.W * c.H);
-  const FrameConst fc = a.fc[f];
-  const float *dprev_f = a.dprev + fN;
-  const uint32_t W = (uint32_t)c.W;
-  int x0[2];
-  bool inb[2];
-  uint32_t o4[2], nib[2] = {0u, 0u};
-  float4 dn[2], dp[2], fa[2], fb[2];
-  double2 rxa[2], rxb[2];
-  const double ry = c.rayy[min(y, c.H - 1)];
-#pragma unroll
-  for (int g = 0; g < 2; g++) {
-    x0[g] = (bx * 128 + g * 64 + lane) * 4;
-    inb[g] = (x0[g] < c.W) && (y < c.H);
-    const uint32_t pix = (uint32_t)min(y, c.H - 1) * W + (uint32_t)min(x0[g], c.W - 4);
-    o4[g] = pix * 4u;
-    dn[g] = ld<float4>(a.dnow + fN, o4[g]);
-    dp[g] = ld<float4>(dprev_f, o4[g]);
-    fa[g] = ld<float4>(a.flow + 2 * fN, pix * 8u);
-    fb[g] = ld<float4>(a.flow + 2 * fN, pix * 8u + 16u);
-    rxa[g] = ld<double2>(c.rayx, (uint32_t)min(x0[g], c.W - 4) * 8u);
-    rxb[g] = ld<double2>(c.rayx, (uint32_t)min(x0[g], c.W - 4) * 8u + 16u);
-  }
-#pragma unroll
-  for (int g = 0; g < 2; g++) {
-    Px p0, p1, p2, p3;
-    PxState s0, s1, s2, s3;
-    const int xg = min(x0[g], c.W - 4);
-    sf_stage1(c, fc, xg + 0, y, dn[g].x, dp[g].x, fa[g].x, fa[g].y, rxa[g].x, ry, p0, s0);
-    sf_stage1(c, fc, xg + 1, y, dn[g].y, dp[g].y, fa[g].z, fa[g].w, rxa[g].y, ry, p1, s1);
-    sf_stage1(c, fc, xg + 2, y, dn[g].z, dp[g].z, fb[g].x, fb[g].y, rxb[g].x, ry, p2, s2);
-    sf_stage1(c, fc, xg + 3, y, dn[g].w, dp[g].w, fb[g].z, fb[g].w, rxb[g].y, ry, p3, s3);
-    if (inb[g]) {
-      st(a.x + fN, o4[g], make_float4(p0.x, p1.x, p2.x, p3.x));
-      st(a.y + fN, o4[g], make_float4(p0.y, p1.y, p2.y, p3.y));
-      st(a.z + fN, o4[g], make_float4(p0.z, p1.z, p2.z, p3.z));
-    }
-    const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
-    const float g1 = ld<float>(dprev_f, ((uint32_t)s1.py * W + (uint32_t)s1.px) * 4u);
-    const float g2 = ld<float>(dprev_f, ((uint32_t)s2.py * W + (uint32_t)s2.px) * 4u);
-    const float g3 = ld<float>(dprev_f, ((uint32_t)s3.py * W + (uint32_t)s3.px) * 4u);
-    const double ax0 = ld<double>(c.rayx, (uint32_t)s0.px * 8u), ax1 = ld<double>(c.rayx, (uint32_t)s1.px * 8u);
-    const double ax2 = ld<double>(c.rayx, (uint32_t)s2.px * 8u), ax3 = ld<double>(c.rayx, (uint32_t)s3.px * 8u);
-    const double ay0 = ld<double>(c.rayy, (uint32_t)s0.py * 8u), ay1 = ld<double>(c.rayy, (uint32_t)s1.py * 8u);
-    const double ay2 = ld<double>(c.rayy, (uint32_t)s2.py * 8u), ay3 = ld<double>(c.rayy, (uint32_t)s3.py * 8u);
-    PxWarp w0, w1, w2, w3;
-    sf_stage2a(c, fc, s0, g0, ax0, ay0, p0, w0);
-    sf_stage2a(c, fc, s1, g1, ax1, ay1, p1, w1);
-    sf_stage2a(c, fc, s2, g2, ax2, ay2, p2, w2);
-    sf_stage2a(c, fc, s3, g3, ax3, ay3, p3, w3);
-    if (__any(w0.todo | w1.todo | w2.todo | w3.todo)) {
-      sf_stage2b(c, fc, s0, w0, p0);
-      sf_stage2b(c, fc, s1, w1, p1);
-      sf_stage2b(c, fc, s2, w2, p2);
-      sf_stage2b(c, fc, s3, w3, p3);
-    }
-    if (inb[g]) {
-      st(a.vx + fN, o4[g], make_float4(p0.vx, p1.vx, p2.vx, p3.vx));
-      st(a.vy + fN, o4[g], make_float4(p0.vy, p1.vy, p2.vy, p3.vy));
-      st(a.vz + fN, o4[g], make_float4(p0.vz, p1.vz, p2.vz, p3.vz));
-      nib[g] = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u) | (p2.dyn ? 4u : 0u) | (p3.dyn ? 8u : 0u);
-    }
-  }
-  if (a.mask) {
-#pragma unroll
-    for (int g = 0; g < 2; g++) {
-      const uint64_t w = nibbles_to_word(nib[g], lane);
-      const int word = (bx * 128 + g * 64 + lane) / 16;
-      if ((lane & 15) == 0 && y < c.H && word < c.mask_words) {
-        a.mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
-        if (a.tilehdr && w) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + word) * 2] = 1;
-      }
-    }
-  }
-}
-#endif
 
 // Even widths that are not a multiple of 4 (the reference's own working resolution is 1242 x 376, detect_with_zed.launch:10):
 // rows are 8-byte aligned, so thread = 2 consecutive pixels (float2 loads / stores, one float4 of flow), wave = 128 px.
@@ -600,13 +471,6 @@ __global__ __launch_bounds__(256) void k_unpack(size_t n, const float4 *aos, flo
 void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s) {
   dim3 block(64, 4, 1);
   if ((c.W & 3) == 0) {
-#ifdef SF_8PX
-    if (!a.aos && !a.depth && !a.sflow && c.W >= 4) {   // the experiment kernel writes the six planes and the mask only
-      dim3 grid8((c.W / 4 + 127) / 128, (c.H + 3) / 4, frames);
-      hipLaunchKernelGGL(k_scene_flow_v8, grid8, block, 0, s, c, a);
-      return;
-    }
-#endif
     dim3 grid((c.W / 4 + 63) / 64, (c.H + 3) / 4, frames);
     hipLaunchKernelGGL(k_scene_flow_v4, grid, block, 0, s, c, a);
   } else if ((c.W & 1) == 0) {

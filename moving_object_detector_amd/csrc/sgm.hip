@@ -246,9 +246,7 @@ __global__ __launch_bounds__(64) void k_sgm_path_line(int W, int H, int D, int P
 // ~70 vector instructions per step of four lines (17 per line step, one-line kernels: ~30) and a shorter dependent chain.
 // The four lines of a wave are neighbours (rows / columns / diagonals next to each other); they may differ in length by a few
 // pixels: a line that has ended keeps computing on its last pixel and stores nothing.
-#ifndef SGM_QPF
-#define SGM_QPF 2   // census slots in flight per line (steps of prefetch)
-#endif
+constexpr int kSgmPrefetch = 2;   // census slots in flight per line (steps of prefetch; 1 .. 4 measured, no difference)
 typedef uint32_t sgm_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t sgm_u2 __attribute__((ext_vector_type(2)));
 // UNIFORM: the wave's four lines exist and have one length (rows / columns of an image whose height / width is a multiple of 4):
@@ -258,7 +256,7 @@ typedef uint32_t sgm_u2 __attribute__((ext_vector_type(2)));
 template <int RX, int RY, bool UNIFORM, bool COST>
 __device__ __forceinline__ void sgm_path_q_body(int W, int H, int P1, int P2, const uint32_t *__restrict__ cl, const uint32_t *__restrict__ cr,
                                                 SgmOut out, int blk, int f) {
-  constexpr int D = 128, kPF = SGM_QPF;
+  constexpr int D = 128, kPF = kSgmPrefetch;
   const int lane = threadIdx.x, q = lane >> 4, t = lane & 15;
   const int nlines = RY == 0 ? H : (RX == 0 ? W : W + H - 1);
   const int line = blk * 4 + q;
@@ -347,21 +345,10 @@ __device__ __forceinline__ void sgm_path_q_body(int W, int H, int P1, int P2, co
         for (int j = 0; j < 4; j++) l[j] = c[j];
       }
       if (UNIFORM || i < len) {                         // lines that have ended store nothing
-#if defined(SGM_EXP) && SGM_EXP == 2   // timing experiment: every store lands in the first megabyte (cache-resident), results are wrong
-        const uint32_t at = ((uint32_t)(yy * W + xx) * (uint32_t)D + (uint32_t)dbase) & 0xFFFFFu;
-#else
         const uint32_t at = (uint32_t)(yy * W + xx) * (uint32_t)D + (uint32_t)dbase;
-#endif
         sgm_u2 v;
         v.x = __builtin_amdgcn_perm(l[1], l[0], 0x06040200u); v.y = __builtin_amdgcn_perm(l[3], l[2], 0x06040200u);
-#if defined(SGM_EXP) && SGM_EXP == 1   // timing experiment: no store at all (kept alive by an impossible condition), results are wrong
-        if (v.x == 0x12345678u && v.y == 0x9abcdef0u)
-#endif
-#ifndef SGM_PLAIN_STORE   // streaming stores: the volume is read once, much later, by another kernel; plain stores push the census words out of L2 (-7 %)
         __builtin_nontemporal_store(v, (SGM_GLOBAL sgm_u2 *)(outL + at));
-#else
-        *(SGM_GLOBAL sgm_u2 *)(outL + at) = v;
-#endif
         if (COST) {
           v.x = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u); v.y = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u);
           *(SGM_GLOBAL sgm_u2 *)(outC + at) = v;
@@ -384,11 +371,8 @@ __global__ __launch_bounds__(64) void k_sgm_path_q(int W, int H, int P1, int P2,
 // runtime maps streams onto 4 hardware queues by default, so only four of the eight path kernels ever ran side by side (kernel
 // trace of round 3) and the short ones queued behind the long ones; inside one grid the dispatcher fills every free wave slot
 // with whatever block is next.  Path i writes its volume at out.L + i * path_stride.
-#ifndef SGM_ALL_ATTR
-#define SGM_ALL_ATTR
-#endif
 template <bool UH, bool UV>
-__global__ __launch_bounds__(64) SGM_ALL_ATTR void k_sgm_paths_all(int W, int H, int P1, int P2, int paths, size_t path_stride, const uint32_t *__restrict__ cl,
+__global__ __launch_bounds__(64) void k_sgm_paths_all(int W, int H, int P1, int P2, int paths, size_t path_stride, const uint32_t *__restrict__ cl,
                                                       const uint32_t *__restrict__ cr, uint8_t *__restrict__ L) {
   const int nh = (H + 3) / 4, nv = (W + 3) / 4, nd = (W + H - 1 + 3) / 4;
   int blk = (int)blockIdx.x;
@@ -468,13 +452,9 @@ __global__ __launch_bounds__(256) void k_sgm_wta16(int W, int H, int D, int path
     if (live) {
       const uint8_t *q = Lv + ((size_t)y * W + x) * D + dbase;
       for (int p = 0; p < paths; p++) {
-#ifndef SGM_PLAIN_LOAD   // streaming loads: the volumes are read exactly once (-4 %)
         typedef uint32_t wta_u4 __attribute__((ext_vector_type(4)));
         const wta_u4 wv_ = __builtin_nontemporal_load(reinterpret_cast<const wta_u4 *>(q + (size_t)p * path_stride));
         uint4 w; w.x = wv_.x; w.y = wv_.y; w.z = wv_.z; w.w = wv_.w;
-#else
-        const uint4 w = *reinterpret_cast<const uint4 *>(q + (size_t)p * path_stride);
-#endif
         e[0] += w.x & 0x00ff00ffu; o[0] += (w.x >> 8) & 0x00ff00ffu;
         e[1] += w.y & 0x00ff00ffu; o[1] += (w.y >> 8) & 0x00ff00ffu;
         e[2] += w.z & 0x00ff00ffu; o[2] += (w.z >> 8) & 0x00ff00ffu;
@@ -557,9 +537,8 @@ void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direct
     case 6: hipLaunchKernelGGL((k_sgm_path_line<-1, 1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                     \
     default: hipLaunchKernelGGL((k_sgm_path_line<1, -1, FULL>), gd, b, 0, s, W, H, D, P1, P2, cl, cr, o); break;                    \
   }
-  // D == 128 (the published configuration): four lines per wave; MOD_SGM_PATH=line keeps the one-line kernels for A/B runs
-  static const bool one_line = [] { const char *e = std::getenv("MOD_SGM_PATH"); return e && std::string(e) == "line"; }();
-  if (D == 128 && !one_line && right_plane_padded) {
+  // D == 128 (the published configuration): four lines per wave; the one-line kernels serve every other disparity count
+  if (D == 128 && right_plane_padded) {
     const dim3 qh((H + 3) / 4, frames), qv((W + 3) / 4, frames), qd((W + H - 1 + 3) / 4, frames);
     const bool uh = (H & 3) == 0, uv = (W & 3) == 0;
 #define SGM_Q(RX, RY, UNI, GRID)                                                                                            \
@@ -587,11 +566,10 @@ void launch_sgm_path(int W, int H, int frames, int D, int P1, int P2, int direct
 }
 
 // every path of the published configuration (D == 128) in one grid; returns false when the combination is not covered (other D,
-// MOD_SGM_PATH=line): the caller then launches the paths one by one
+// other path counts): the caller then launches the paths one by one
 bool launch_sgm_paths_all(int W, int H, int frames, int D, int P1, int P2, int paths, size_t path_stride, const uint32_t *cl, const uint32_t *cr,
                           uint8_t *L, hipStream_t s) {
-  static const bool one_line = [] { const char *e = std::getenv("MOD_SGM_PATH"); return e && (std::string(e) == "line" || std::string(e) == "streams"); }();
-  if (D != 128 || one_line || (paths != 8 && paths != 4)) return false;
+  if (D != 128 || (paths != 8 && paths != 4)) return false;
   const int nh = (H + 3) / 4, nv = (W + 3) / 4, nd = (W + H - 1 + 3) / 4;
   const dim3 g(2 * nh + 2 * nv + (paths == 8 ? 4 * nd : 0), frames), b(64);
   const bool uh = (H & 3) == 0, uv = (W & 3) == 0;

@@ -46,7 +46,9 @@ def init_group(backend: str, rank: int, world: int, device=None, port: int | Non
             raise RuntimeError("MASTER_PORT is not set: start the ranks with a launcher (torch.distributed.run, launch.spawn_ranks)")
         from .launch import free_port
         os.environ["MASTER_PORT"] = str(port or free_port())
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (HSA_ENABLE_IPC_MODE_LEGACY=0, which RCCL needs across processes on this pool's driver, has to be in the environment BEFORE
+    # the ROCm runtime loads, i.e. before `import torch`: bench.py sets it at import, launch.spawn_ranks in the children's
+    # environment; setting it here would be too late to matter.)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     else:

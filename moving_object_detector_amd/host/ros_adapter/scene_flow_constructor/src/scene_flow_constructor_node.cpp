@@ -10,6 +10,15 @@
 //                    collect(); the disparity plane stays in HBM as the next frame's previous one (:397-398)
 //   optical flow     CALL-OUT estimateOpticalFlow(): the reference asks pwc_net (:281-291); not part of this package
 //   camera motion    CALL-OUT estimateCameraMotion(): the reference runs libviso2 and a TF lookup (:214-256); not part of this package
+//   clustering       on the GPU, IN THIS PROCESS, when `~publish_moving_objects` is true (default): the node then advertises
+//                    `~moving_objects` itself (what the separate scene_flow_clusterer publishes, clusterer_nodelet.cpp:324-343) from the
+//                    planes that are still in HBM — one clustering per frame, no 29.5 MB PointCloud2 hand-off between two processes
+//                    (detect_moving_object.launch:19-33 wires constructor -> topic -> clusterer; INTEGRATION.md section 3 has the two
+//                    launch-file lines that drop the separate clusterer).  The clusterer's four parameters are read from
+//                    `~clusterer/{cluster_size, depth_diff, dynamic_speed, neighbor_distance}` (Clusterer.cfg defaults) and served by a
+//                    second dynamic_reconfigure server in that namespace.  With the parameter false the node is the reference's
+//                    constructor alone: no clustering runs here.
+//   ~scene_flow      the 32-byte cloud is packed and copied to the host only while somebody subscribes (:141-142 gates exactly so)
 // Not buildable in the image this was written in (no ROS): tests/test_ros_adapter_syntax.py compiles it against declaration-only
 // stand-ins of the ROS headers; behaviour lives in the host mirror (moving_object_detector_amd/host/scene_flow_constructor.hpp) and the C ABI, which are tested.
 #include <dynamic_reconfigure/server.h>
@@ -18,7 +27,9 @@
 #include <image_transport/subscriber_filter.h>
 #include <message_filters/subscriber.h>
 #include <message_filters/time_synchronizer.h>
+#include <moving_object_msgs/MovingObjectArray.h>
 #include <ros/ros.h>
+#include <scene_flow_clusterer/ClustererConfig.h>
 #include <scene_flow_constructor/SceneFlowConstructorConfig.h>
 #include <sensor_msgs/CameraInfo.h>
 #include <sensor_msgs/Image.h>
@@ -63,6 +74,17 @@ class SceneFlowConstructorNode {
     optflow_pub_ = private_node_handle_.advertise<sensor_msgs::Image>("optical_flow", 1);
     pc_with_velocity_pub_ = private_node_handle_.advertise<sensor_msgs::PointCloud2>("scene_flow", 1);
     static_flow_pub_ = private_node_handle_.advertise<sensor_msgs::Image>("synthetic_optical_flow", 1);
+
+    // collapsed mode: this process clusters too and publishes the moving objects (see the header comment)
+    publish_moving_objects_ = private_node_handle_.param("publish_moving_objects", true);
+    if (publish_moving_objects_) {
+      clusterer_node_handle_ = ros::NodeHandle(private_node_handle_, "clusterer");
+      clusterer_reconfigure_server_.reset(new dynamic_reconfigure::Server<scene_flow_clusterer::ClustererConfig>(clusterer_node_handle_));
+      clusterer_reconfigure_server_->setCallback([this](scene_flow_clusterer::ClustererConfig &config, uint32_t) {
+        impl_->reconfigureClusterer(config.cluster_size, config.depth_diff, config.dynamic_speed, config.neighbor_distance);
+      });
+      moving_objects_pub_ = private_node_handle_.advertise<moving_object_msgs::MovingObjectArray>("moving_objects", 1);
+    }
 
     // subscribers + exact-time synchroniser, queue 1 (:51-62)
     const std::string left_image_topic = node_handle_.resolveName("left_image"), right_image_topic = node_handle_.resolveName("right_image");
@@ -136,8 +158,12 @@ class SceneFlowConstructorNode {
     // ~depth and ~synthetic_optical_flow are debugging views the reference renders only for subscribers (:114,141); they need the
     // disparity on the host, which the streaming path avoids: when somebody listens, this frame's disparity is fetched as well
     const bool want_views = depth_pub_.getNumSubscribers() > 0 || static_flow_pub_.getNumSubscribers() > 0;
-    pending_cloud_.reset(new mod_host::PointCloud2());
-    pending_ticket_ = impl_->submitStereo(&l, &r, left_flow ? &f : nullptr, transform_prev2now ? &t : nullptr, pending_cloud_.get(), nullptr);
+    // outputs asked for THIS frame, gated like the reference's publishes: the cloud only while ~scene_flow has subscribers
+    // (:141-142), the objects while the collapsed mode is on and ~moving_objects has subscribers (clusterer_nodelet.cpp:237-238);
+    // with neither, the frame still goes through the scene-flow stage so that its disparity is the next frame's previous one
+    pending_cloud_.reset(pc_with_velocity_pub_.getNumSubscribers() > 0 ? new mod_host::PointCloud2() : nullptr);
+    pending_objects_.reset(publish_moving_objects_ && moving_objects_pub_.getNumSubscribers() > 0 ? new mod_host::MovingObjectArray() : nullptr);
+    pending_ticket_ = impl_->submitStereo(&l, &r, left_flow ? &f : nullptr, transform_prev2now ? &t : nullptr, pending_cloud_.get(), pending_objects_.get());
     pending_header_ = left_flow ? left_flow->header : left_image->header;
     pending_keep_ = {left_image, right_image, left_flow};           // the buffers stay alive until the frame is collected
     if (want_views) publishViews(l, r, *left_camera_info, *right_camera_info, left_image->header, transform_prev2now ? &t : nullptr);
@@ -150,7 +176,22 @@ class SceneFlowConstructorNode {
     if (pending_ticket_ < 0) return;
     impl_->collect(pending_ticket_);
     pending_ticket_ = -1;
-    if (pc_with_velocity_pub_.getNumSubscribers() > 0) {              // publishPointcloud (:351-362), gated as :144
+    if (pending_objects_) {                                           // publishMovingObjects (clusterer_nodelet.cpp:324-343)
+      moving_object_msgs::MovingObjectArray m;
+      m.header = pending_header_;
+      for (const auto &o : pending_objects_->moving_object_array) {
+        moving_object_msgs::MovingObject mo;
+        mo.id = o.id;
+        mo.center.position.x = o.center.position[0]; mo.center.position.y = o.center.position[1]; mo.center.position.z = o.center.position[2];
+        mo.center.orientation.x = 0; mo.center.orientation.y = 0; mo.center.orientation.z = 0; mo.center.orientation.w = 1;
+        mo.velocity.x = o.velocity[0]; mo.velocity.y = o.velocity[1]; mo.velocity.z = o.velocity[2];
+        mo.bounding_box.x = o.bounding_box[0]; mo.bounding_box.y = o.bounding_box[1]; mo.bounding_box.z = o.bounding_box[2];
+        m.moving_object_array.push_back(mo);
+      }
+      moving_objects_pub_.publish(m);
+      pending_objects_.reset();
+    }
+    if (pending_cloud_) {                                             // publishPointcloud (:351-362); asked for because somebody subscribed (:144)
       sensor_msgs::PointCloud2 msg;   // fields x, y, z, vx, vy, vz float32 at 0, 4, 8, 16, 20, 24 (pcl_point_xyz_velocity.h:27-34)
       msg.header = pending_header_; msg.width = pending_cloud_->width; msg.height = pending_cloud_->height;
       msg.point_step = 32; msg.row_step = pending_cloud_->row_step; msg.is_dense = true; msg.is_bigendian = false;
@@ -197,7 +238,11 @@ class SceneFlowConstructorNode {
   image_transport::SubscriberFilter left_image_sub_, right_image_sub_;
   message_filters::Subscriber<sensor_msgs::CameraInfo> left_caminfo_sub_, right_caminfo_sub_;
   std::unique_ptr<StereoSynchronizer> stereo_synchronizer_;
-  ros::Publisher depth_pub_, optflow_pub_, pc_with_velocity_pub_, static_flow_pub_;
+  ros::Publisher depth_pub_, optflow_pub_, pc_with_velocity_pub_, static_flow_pub_, moving_objects_pub_;
+  bool publish_moving_objects_ = true;
+  ros::NodeHandle clusterer_node_handle_;
+  std::unique_ptr<dynamic_reconfigure::Server<scene_flow_clusterer::ClustererConfig>> clusterer_reconfigure_server_;
+  std::unique_ptr<mod_host::MovingObjectArray> pending_objects_;
   bool camera_set_ = false;
   float max_disparity_ = 127.0f;
   sensor_msgs::ImageConstPtr previous_left_image_;

@@ -46,6 +46,14 @@ class SceneFlowConstructor {
     check(mod_set_params(ctx_, &p));
   }
 
+  // The clusterer's reconfigureCB (clusterer_nodelet.cpp:345-352) for a process that runs both stages on one context (the collapsed
+  // node: `~publish_moving_objects`): the four Clusterer.cfg values go into the shared ModParams block, dynamic_flow_diff is preserved.
+  void reconfigureClusterer(int cluster_size, double depth_diff, double dynamic_speed, int neighbor_distance) {
+    ModParams p = currentParams();
+    p.cluster_size = cluster_size; p.depth_diff = depth_diff; p.dynamic_speed = dynamic_speed; p.neighbor_distance = neighbor_distance;
+    check(mod_set_params(ctx_, &p));
+  }
+
   // estimateDisparity() (scene_flow_constructor.cpp:258-279): sgm_gpu_->computeDisparity(left, right, infos, disparity).  Fills
   // `disparity` as that call does for its caller — the stereo_msgs/DisparityImage contract DisparityImageProcessor reads
   // (disparity_image_processor.cpp:25-27,41-45): 32FC1 pixels with -1 = min_disparity - 1 where no match was found, f from the
@@ -165,10 +173,11 @@ class SceneFlowConstructor {
       Pending &p = pending_[next_slot_];
       p.objects.resize(max_objects_);
       // previous disparity: resident in HBM from the last enqueued frame, or the host copy parked by a skipped frame
+      // moving_objects == nullptr: no cluster output is asked for and the library runs the scene-flow stage alone
       rc = mod_submit_frame_host(ctx_, disparity_now->data, have_parked_ ? parked_.data() : nullptr,
                                  left_flow ? left_flow->data : nullptr, transform_prev2now ? &tf : nullptr, dt,
-                                 pc_with_velocity ? pc_with_velocity->data.data() : nullptr, nullptr, p.objects.data(),
-                                 (int32_t)p.objects.size(), &ticket);
+                                 pc_with_velocity ? pc_with_velocity->data.data() : nullptr, nullptr, moving_objects ? p.objects.data() : nullptr,
+                                 moving_objects ? (int32_t)p.objects.size() : 0, &ticket);
       if (rc == MOD_OK) {
         p.ticket = ticket; p.cloud = pc_with_velocity; p.objs = moving_objects; p.header = left_flow->header;
         next_slot_ = (next_slot_ + 1) % MOD_PIPELINE_DEPTH;
@@ -210,10 +219,12 @@ class SceneFlowConstructor {
     Pending &p = pending_[next_slot_];
     p.objects.resize(max_objects_);
     int32_t ticket = -1;
+    // pc_with_velocity == nullptr: the 32-byte cloud is neither packed nor copied to the host (nobody subscribes to ~scene_flow);
+    // moving_objects == nullptr: no cluster output is asked for and the library runs the scene-flow stage alone
     const int rc = mod_submit_stereo_host(ctx_, images ? left_image->data : nullptr, images ? right_image->data : nullptr, &sgm_,
                                           left_flow ? left_flow->data : nullptr, transform_prev2now ? &tf : nullptr, dt,
-                                          pc_with_velocity ? pc_with_velocity->data.data() : nullptr, nullptr, p.objects.data(),
-                                          (int32_t)p.objects.size(), nullptr, &ticket);
+                                          pc_with_velocity ? pc_with_velocity->data.data() : nullptr, nullptr, moving_objects ? p.objects.data() : nullptr,
+                                          moving_objects ? (int32_t)p.objects.size() : 0, nullptr, &ticket);
     have_parked_ = false;                         // the previous disparity lives in HBM (or is gone with the images)
     if (images) { previous_stamp_ = left_image->header.stamp; have_stamp_ = true; }
     else have_stamp_ = false;

@@ -20,7 +20,7 @@ def main():
     from oracle import pyoracle
     from util import PLANES, bits_equal, compare_objects
 
-    counters = np.zeros(64, np.uint64)
+    counters = np.zeros(96, np.uint64)
     ran = []
 
     def run(name, cam, prm, batch, check_frames):
@@ -35,7 +35,7 @@ def main():
         for _ in range(2):                                   # twice: the second pass runs over scratch the first one left behind
             assert ctx.process(b, ws) == 0
             ctx.synchronize()
-        out = (C.c_uint64 * 64)()
+        out = (C.c_uint64 * 96)()
         ctx.lib.mod_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         assert ctx.lib.mod_debug_counters(ctx.h, out) == 0
         counters[:] += np.frombuffer(out, np.uint64)
@@ -92,7 +92,7 @@ def main():
         for _ in range(2):
             assert ctx.cluster(1, ws, mask_ready=False) == 0
             ctx.synchronize()
-        out = (C.c_uint64 * 64)()
+        out = (C.c_uint64 * 96)()
         ctx.lib.mod_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         assert ctx.lib.mod_debug_counters(ctx.h, out) == 0
         counters[:] += np.frombuffer(out, np.uint64)
@@ -101,7 +101,7 @@ def main():
         compare_objects(ctx.objects_to_host(ws)[0], ro, strict_velocity=True)
         ctx.close()
         ran.append(f"wide tied cluster {W}x{H}, no labels plane")
-    print(json.dumps({"ran": ran, "violations": {str(i - 48): int(v) for i, v in enumerate(counters) if i >= 48}}))
+    print(json.dumps({"ran": ran, "violations": {str(i - 64): int(v) for i, v in enumerate(counters) if i >= 64}}))
 
 
 if __name__ == "__main__":

@@ -131,6 +131,38 @@ int main(int argc, char **argv) {
     if (c3.data != c3s.data) { fprintf(stderr, "pipelined frame after a skipped one differs\n"); return 13; }
   }
 
+  // SURVEY.md 8(f)2, the collapsed node: the objects of the FUSED path (constructor context, planes still in HBM) are the nodelet
+  // path's (PointCloud2 through the wire, clustered again) byte for byte ...
+  for (size_t i = 0; i < objs_cluster.moving_object_array.size(); i++) {
+    const mod_host::MovingObject &a = objs_fused.moving_object_array[i], &b = objs_cluster.moving_object_array[i];
+    if (a.id != b.id || memcmp(&a.center, &b.center, sizeof(a.center)) || memcmp(a.velocity, b.velocity, sizeof(a.velocity)) ||
+        memcmp(a.bounding_box, b.bounding_box, sizeof(a.bounding_box))) { fprintf(stderr, "fused object %zu differs from the nodelet's\n", i); return 30; }
+  }
+  // ... and a frame submitted WITHOUT cluster outputs (nobody subscribes to ~moving_objects) does not launch the cluster stage at
+  // all, while one with them launches it once: stage timers of the context
+  {
+    scene_flow_constructor::SceneFlowConstructor quiet(ctx);
+    quiet.setCameraInfo(info, now);
+    mod_host::PointCloud2 cq;
+    mod_host::MovingObjectArray oq;
+    double ms = 0.0; int64_t calls = -1;
+    if (mod_set_profiling(ctx, MOD_PROFILE_ALL) != MOD_OK || mod_reset_stage_times(ctx) != MOD_OK) return 31;
+    const int q0 = quiet.submit(&prev, nullptr, nullptr, nullptr, nullptr);
+    const int q1 = quiet.submit(&now, &fl, &tf, &cq, nullptr);           // the cloud alone
+    if (q0 != -1 || q1 < 0) { fprintf(stderr, "quiet ticket pattern wrong: %d %d\n", q0, q1); return 32; }
+    quiet.collect(q1);
+    if (mod_get_stage_time(ctx, MOD_STAGE_CCL_TILE, &ms, &calls) != MOD_OK || calls != 0) { fprintf(stderr, "cluster stage ran without cluster outputs: %lld calls\n", (long long)calls); return 33; }
+    if (mod_get_stage_time(ctx, MOD_STAGE_SCENE_FLOW, &ms, &calls) != MOD_OK || calls != 1) { fprintf(stderr, "scene-flow stage calls: %lld\n", (long long)calls); return 34; }
+    if (cq.data != cloud.data) { fprintf(stderr, "cloud of the scene-flow-only submit differs\n"); return 35; }
+    mod_host::DisparityImage later = now;
+    later.header.stamp = mod_host::Time::fromSec(now.header.stamp.toSec() + tq[7]);
+    const int q2 = quiet.submit(&later, &fl, &tf, nullptr, &oq);          // the objects alone: no cloud is packed or copied
+    if (q2 < 0) { fprintf(stderr, "objects-only submit refused\n"); return 36; }
+    quiet.collect(q2);
+    if (mod_get_stage_time(ctx, MOD_STAGE_CCL_TILE, &ms, &calls) != MOD_OK || calls != 1) { fprintf(stderr, "cluster stage calls with objects asked for: %lld\n", (long long)calls); return 37; }
+    if (mod_set_profiling(ctx, 0) != MOD_OK) return 38;
+  }
+
   write_all(dir + "/cloud.bin", cloud.data.data(), cloud.data.size());
   write_all(dir + "/labels.i32", cluster_map.data(), cluster_map.size() * 4);
   std::vector<double> o;

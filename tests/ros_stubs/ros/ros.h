@@ -17,6 +17,7 @@ class NodeHandle {
  public:
   NodeHandle();
   explicit NodeHandle(const std::string &ns);
+  NodeHandle(const NodeHandle &parent, const std::string &ns);   // roscpp: child handle in a sub-namespace
   template <class T> T param(const std::string &name, const T &default_value) const;
   std::string resolveName(const std::string &name) const;
   template <class M> Publisher advertise(const std::string &topic, uint32_t queue_size);

@@ -122,3 +122,18 @@ def test_only_k_final_touches_the_optional_labels_plane():
         if re.search(r"\ba\.labels\s*\[", line):                     # an access: guarded on this line or by the enclosing `if (a.labels)`
             ctx = " ".join(lines[max(0, i - 2): i + 1])
             assert re.search(r"if\s*\(\s*a\.labels\b", ctx), f"cluster.hip:{i + 1}: unguarded access to the labels plane"
+
+
+def test_product_library_has_no_hidden_switches_or_experiment_kernels():
+    """A drop-in library does not change behaviour by environment: the product build reads no environment variable and carries no
+    experiment kernel (round 3 shipped five getenv knobs, the slower one-wave tile kernel and an 8-px scene-flow variant)."""
+    from moving_object_detector_amd import capi
+    blob = open(os.path.join(ROOT, "moving_object_detector_amd", "libmod_sf.so"), "rb").read()
+    for name in (b"MOD_TILE_KERNEL", b"MOD_SGM_PATH", b"MOD_SGM_GROUP", b"MOD_SGM_CU_KEEP", b"MOD_DEBUG", b"k_ccl_rows", b"k_scene_flow_v8"):
+        assert name not in blob, name
+    srcs = [os.path.join(ROOT, "moving_object_detector_amd", "csrc", f) for f in ("mod_sf.hip", "cluster.hip", "sceneflow.hip", "sgm.hip")]
+    for path in srcs:
+        for i, line in enumerate(open(path), 1):
+            if "getenv" in line:
+                # the one permitted use sits behind the diagnostic-build macros
+                assert "MOD_DEBUG" in line and path.endswith("mod_sf.hip"), (path, i)

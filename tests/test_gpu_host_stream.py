@@ -244,3 +244,38 @@ def test_stereo_and_disparity_submissions_share_the_ring():
     assert np.array_equal(lab1, lab0)
     assert np.array_equal(cloud1.view(np.uint32)[:, [0, 1, 2, 4, 5, 6]], cloud0.view(np.uint32)[:, [0, 1, 2, 4, 5, 6]])
     assert bytes(objs1)[: 112 * n1] == bytes(objs0)[: 112 * n1]
+
+
+def test_disparity_copy_survives_guard_skipped_frames_that_wrap_the_ring():
+    """A ticketed stereo frame asks for its disparity plane on the host; before it is collected, MOD_PIPELINE_DEPTH + 1 frames that end
+    at a guard (no flow: a ring plane each, no ticket) bring the ring back to that plane, and the last one's estimator overwrites it
+    with ANOTHER image pair's disparity.  The plane's writer has to wait for the copy: the host buffer must hold the first pair's
+    disparity."""
+    import os
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "sgm_320x240.npz"))
+    H, W = g["left"].shape
+    D, N, CAP = 128, H * W, 32
+    left, right = np.ascontiguousarray(g["left"]), np.ascontiguousarray(g["right"])
+    other_l, other_r, _ = synth.make_stereo_images(W, H, 5, D)          # a different scene
+    cam = synth.make_camera(W, H)
+    cam.min_disparity, cam.max_disparity = np.float32(0.0), np.float32(D - 1)
+    sp = capi.ModSgmParams(D, 6, 96, 8, 1, 1)
+    flow = synth.make_box_flow(g["truth"], shift=14.0)
+    tf = capi.transforms_array(np.zeros((1, 3)), np.array([[0.0, 0.0, 0.0, 1.0]]))
+    dt = 1.0 / 15.0
+    ctx = Context(W, H, max_frames=1)
+    ctx.set_camera(cam); ctx.set_params(synth.Params(cluster_size=150))
+    t, n = C.c_int32(-1), C.c_int32(-1)
+    sub = lambda l, r, fl, d: ctx.lib.mod_submit_stereo_host(ctx.h, l.ctypes.data, r.ctypes.data, C.byref(sp), fl, C.byref(tf[0]), dt, None, None, None, 0, d, C.byref(t))
+    assert sub(left, right, None, None) == capi.MOD_SKIP_NO_FLOW         # gives the next frame its previous disparity
+    disp = torch.zeros((H, W), dtype=torch.float32).pin_memory().numpy() # pinned: the copy really is asynchronous
+    assert sub(left, right, flow.ctypes.data, disp.ctypes.data) == 0, ctx.lib.mod_last_error(ctx.h)
+    ticket = t.value
+    for k in range(capi.MOD_PIPELINE_DEPTH + 1):                         # the ring has DEPTH + 1 planes: the last of these is the ticketed frame's
+        assert sub(other_l, other_r, None, None) == capi.MOD_SKIP_NO_FLOW
+    assert ctx.lib.mod_collect_frame_host(ctx.h, ticket, C.byref(n)) == 0
+    ctx.synchronize()
+    ctx.close()
+    assert np.array_equal(disp, g["disparity"])

@@ -117,3 +117,37 @@ def test_one_rank_group_runs_the_same_collectives_on_gloo():
         e.pop(k, None)
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def _torchrun_bench(n, *argv, drop=("HSA_ENABLE_IPC_MODE_LEGACY",)):
+    from moving_object_detector_amd.launch import free_port
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT") + tuple(drop):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+                           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), *argv],
+                          env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_external_launcher_rank_gets_the_ipc_variable_before_torch_loads():
+    # the driver's own command (torch.distributed.run ... bench.py) from an environment WITHOUT the variable: bench.py sets it at
+    # import, before torch (and with it the ROCm runtime) is loaded, and takes the process group down before rank 0's solo legs
+    r = _torchrun_bench(2, "--launch-check", "--distinct", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["ipc_env_set_before_torch"] is True and j["hsa_enable_ipc_mode_legacy"] == "0"
+    assert j["group_down_before_solo_legs"] is True
+
+
+def test_failed_rank_is_fatal_and_visible():
+    r = _torchrun_bench(2, "--launch-check", "--distinct", "3", "--fail-rank", "1", drop=())
+    assert r.returncode != 0
+    assert "bench.py: rank 1 failed: RuntimeError" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no partial JSON
+
+
+def test_cpu_baseline_uses_every_core_of_the_box():
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    ast.parse(src)
+    assert "min(cores, 64)" not in src and "sched_getaffinity" in src

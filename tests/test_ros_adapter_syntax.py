@@ -35,6 +35,11 @@ def test_constructor_node_keeps_the_reference_interface():
         assert name in src, name
     assert src.count("getNumSubscribers() > 0") >= 4
     assert "estimateOpticalFlow" in src and "estimateCameraMotion" in src and "CALL-OUT" in src
+    # collapsed mode: one clustering per frame in this process, ~moving_objects published here, the 29.5 MB cloud
+    # asked for only while ~scene_flow has subscribers (scene_flow_constructor.cpp:141-142)
+    assert 'param("publish_moving_objects", true)' in src and '"moving_objects"' in src
+    assert "pc_with_velocity_pub_.getNumSubscribers() > 0 ? new mod_host::PointCloud2() : nullptr" in src
+    assert "moving_objects_pub_.getNumSubscribers() > 0 ? new mod_host::MovingObjectArray() : nullptr" in src
 
 
 def test_packaging():
@@ -53,7 +58,11 @@ def test_packaging():
         for header_pkg in ("dynamic_reconfigure", "sensor_msgs", "roscpp"):
             assert header_pkg in deps, (pkg, header_pkg)
         if "moving_object_msgs/" in src:
-            assert "moving_object_msgs" in deps and "nodelet" in deps and "pluginlib" in deps
+            assert "moving_object_msgs" in deps
+        if "nodelet/" in src:
+            assert "nodelet" in deps and "pluginlib" in deps
+        if "scene_flow_clusterer/ClustererConfig.h" in src and pkg != "scene_flow_clusterer":
+            assert "scene_flow_clusterer" in deps
         if "image_transport/" in src:
             assert "image_transport" in deps and "message_filters" in deps
     xml.dom.minidom.parse(os.path.join(ADAPTER, "scene_flow_clusterer", "nodelet_plugins.xml"))

@@ -16,7 +16,7 @@ b = ctx.make_batch(torch.from_numpy(host["disparity_now"]).to(dev)[idx].contiguo
                    torch.from_numpy(host["flow"]).to(dev)[idx].contiguous(), host["t"][idx], host["q"][idx], host["dt"][idx])
 lib = ctx.lib
 lib.mod_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-out = (C.c_uint64 * 64)()
+out = (C.c_uint64 * 96)()
 for it in range(3):
     ctx.process(b, ws); ctx.synchronize()
     lib.mod_debug_counters(ctx.h, out)

@@ -10,7 +10,7 @@ ctx = Context(W, H, max_frames=1); ctx.set_camera(cam); ctx.set_params(synth.Par
 dev = ctx.device
 b = ctx.make_batch(torch.from_numpy(host["disparity_now"]).to(dev), torch.from_numpy(host["disparity_prev"]).to(dev), torch.from_numpy(host["flow"]).to(dev), host["t"], host["q"], host["dt"])
 lib = ctx.lib; lib.mod_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-out = (C.c_uint64 * 64)()
+out = (C.c_uint64 * 96)()
 for it in range(3):
     ctx.process(b, ws); ctx.synchronize(); lib.mod_debug_counters(ctx.h, out)
 names = ["bbox", "count", "fill+keys", "-", "hbm levels", "lds levels+finish"]
