@@ -691,6 +691,11 @@ __device__ __forceinline__ Row3 fill_up(Row3 c, Row3 s) {
 }
 __device__ __forceinline__ int popc3(Row3 v) { return __popc(v.h) + __popc(v.a) + __popc(v.b); }
 
+// min / max of depths that are never signalling NaNs where it matters: a dynamic cell's depth is a number (checked for a caller's
+// cloud, guaranteed by the fused kernel) and everything else has been replaced by a quiet NaN, which v_min / v_max pass over —
+// the plain instructions, without the canonicalising v_max x, x that fminf / fmaxf put in front of every loaded value
+__device__ __forceinline__ float zmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float zmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // the F32 of lane l (v_readlane moves bit patterns; the builtin is typed int)
 __device__ __forceinline__ float lane_f32(float v, int l) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); }
 __device__ __forceinline__ float wave_fmin(float v) {
@@ -716,6 +721,13 @@ __device__ __forceinline__ uint64_t lane_bits(uint32_t lo, uint32_t hi, int l) {
 
 constexpr int kTilesPerBlock = 4, kMaxClasses = 4;
 
+// Global accesses of this kernel: ONE wave-uniform base per plane (frame's plane, in SGPRs) + a 32-bit byte offset per lane — the
+// `global_load / global_store v, v_off, s[base]` form.  (A frame's planes span less than 2^29 bytes: mod_create caps W * H at 2^27.)
+// Written as base + zext(offset) with the row's share folded into the OFFSET: left to itself the compiler adds the lane offset to
+// the base first and then keeps one 64-bit VGPR address per row alive across the class loop (32 registers for the 16 parent rows).
+template <class T> __device__ __forceinline__ T ldo(const void *base, uint32_t byte_off) { return *(const T *)((const char *)base + byte_off); }
+template <class T> __device__ __forceinline__ void sto(void *base, uint32_t byte_off, T v) { *(T *)((char *)base + byte_off) = v; }
+
 __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClArgs a, int tiles_x, int tiles_y) {
   const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
   const int wi = blockIdx.x * kTilesPerBlock + wv, ty = blockIdx.y, f = blockIdx.z;
@@ -739,7 +751,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
   const bool il = lane >= HL && lane < PH;                             // a tile row
   const float th = c.depth_th, qnan = __uint_as_float(0x7fc00000u);
   // (uniform row base + 32-bit lane offset: the `global_load v, v_off, s[base]` form, no 64-bit address arithmetic per lane)
-  const uint32_t oc = 4u * (uint32_t)min(x0 + lane, W - 1), oh = 4u * (uint32_t)max(x0 - HL + min(lane, HL - 1), 0);
+  const uint32_t oc = 4u * (uint32_t)min(x0 + lane, W - 1);
   uint32_t rootA = 0u, rootB = 0u;                                     // root bits of the tile rows (lane = row)
   int nreq = 0;
   uint2 *req = a.requests + tix * a.req_cap;
@@ -753,42 +765,52 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
   // is not clear of the next one, when more than kMaxClasses are needed, or when a dynamic cell has a NaN depth (NaN links with
   // everything).  One class — a tile inside one object — is the usual case; object rims have two. --------------------------------
   // The depths of the grid are read from HBM once: the first sweep (smallest / largest depth of the tile) works on them as they
-  // arrive and parks them in LDS (5.4 KB per wave) for the sweeps of a tile with more than one class.
-  __shared__ float zlds[kTilesPerBlock][PH][64 + HL];
-  float(*zl)[64 + HL] = zlds[wv];
-  const int hcol = 64 + min(lane, HL - 1);                             // lanes 3 .. 63 all hold (and store) the halo column x0 - 1
-  float lo = qnan, hi = qnan;
-  uint64_t nanb = 0ull;
+  // arrive and parks the 64 tile columns in LDS (5 KB per wave) for the sweeps of a tile with more than one class.  The four halo
+  // columns stay in registers in the ROW's lane (lane = row: four loads serve all 20 rows), next to the row's halo bits.
+  const float *zplane = a.z + fN;
+  __shared__ float zlds[kTilesPerBlock][PH][64];
+  float(*zl)[64] = zlds[wv];
+  float zh[HL];
   {
-    constexpr int HB = PH / 2;                                         // two batches of 10 rows: 20 loads in flight, 20 registers
+    const int gy = min(max(y0 - HL + lane, 0), H - 1);                 // (lanes >= PH read the clamped last row: never used)
+    const uint32_t ho = 4u * (uint32_t)(gy * W + max(x0 - HL, 0));     // wi == 0 has no halo columns (Mrem.h == 0)
+#pragma unroll
+    for (int j = 0; j < HL; j++) zh[j] = ldo<float>(zplane, ho + 4u * j);
+  }
+  float lo = qnan, hi = qnan;
+  {
+    uint64_t nanb = 0ull;
+    constexpr int HB = PH / 2;                                         // two batches of 10 rows
 #pragma unroll
     for (int g0 = 0; g0 < PH; g0 += HB) {
-      float zr[HB], zh[HB];
+      float zr[HB];
 #pragma unroll
       for (int i = 0; i < HB; i++) {
         const int gy = min(max(y0 - HL + g0 + i, 0), H - 1);
-        const char *row = (const char *)(a.z + fN + (size_t)gy * W);
-        zr[i] = *(const float *)(row + oc);
-        zh[i] = *(const float *)(row + oh);
+        zr[i] = ldo<float>(zplane, oc + 4u * (uint32_t)(gy * W));
       }
 #pragma unroll
       for (int i = 0; i < HB; i++) {
         const int gr = g0 + i;
         const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
-        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)Mrem.h, gr) >> 28));
-        const float z1 = dyn ? zr[i] : qnan, z2 = hdyn ? zh[i] : qnan;
-        lo = fminf(lo, fminf(z1, z2));
-        hi = fmaxf(hi, fmaxf(z1, z2));
+        const float z1 = dyn ? zr[i] : qnan;
+        lo = zmin(lo, z1); hi = zmax(hi, z1);
         zl[gr][lane] = zr[i];
-        zl[gr][hcol] = zh[i];
         // the fused scene-flow kernel never marks a pixel without a finite depth as dynamic; a caller's cloud may
-        if (!a.xy_from_z) nanb |= __ballot((dyn & (zr[i] != zr[i])) | (hdyn & (zh[i] != zh[i])));
+        if (!a.xy_from_z) nanb |= __ballot(dyn & (zr[i] != zr[i]));
       }
     }
-  }
-  if (nanb != 0ull) {                                                  // wave-uniform
-    if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;
-    return;
+#pragma unroll
+    for (int j = 0; j < HL; j++) {
+      const bool hd = (Mrem.h >> (28 + j)) & 1u;
+      const float z2 = hd ? zh[j] : qnan;
+      lo = zmin(lo, z2); hi = zmax(hi, z2);
+      if (!a.xy_from_z) nanb |= __ballot(hd & (zh[j] != zh[j]));
+    }
+    if (nanb != 0ull) {                                                // wave-uniform: NaN links with everything
+      if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;
+      return;
+    }
   }
   for (int pass = 0;; pass++) {                                        // wave-uniform
     if (pass == kMaxClasses) { bail = true; break; }
@@ -797,10 +819,13 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
 #pragma unroll 5
       for (int gr = 0; gr < PH; gr++) {
         const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
-        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)Mrem.h, gr) >> 28));
-        const float z1 = dyn ? zl[gr][lane] : qnan, z2 = hdyn ? zl[gr][hcol] : qnan;
-        lo = fminf(lo, fminf(z1, z2));
-        hi = fmaxf(hi, fmaxf(z1, z2));
+        const float z1 = dyn ? zl[gr][lane] : qnan;
+        lo = zmin(lo, z1); hi = zmax(hi, z1);
+      }
+#pragma unroll
+      for (int j = 0; j < HL; j++) {
+        const float z2 = ((Mrem.h >> (28 + j)) & 1u) ? zh[j] : qnan;
+        lo = zmin(lo, z2); hi = zmax(hi, z2);
       }
     }
     lo = wave_fmin(lo); hi = wave_fmax(hi);
@@ -812,14 +837,18 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
 #pragma unroll 5
       for (int gr = 0; gr < PH; gr++) {
         const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
-        const bool hdyn = __builtin_amdgcn_inverse_ballot_w64((uint64_t)((uint32_t)__builtin_amdgcn_readlane((int)Mrem.h, gr) >> 28));
-        const float z1 = zl[gr][lane], z2 = zl[gr][hcol];
-        const bool in1 = dyn & !(z1 - lo > th), in2 = hdyn & !(z2 - lo > th);
+        const float z1 = zl[gr][lane];
+        const bool in1 = dyn & !(z1 - lo > th);
         const uint64_t b1 = __ballot(in1);
-        const uint32_t b2 = (uint32_t)__ballot(in2) << 28;
-        const bool me = lane == gr;                                    // into the row's lane (three selects)
-        M.a = me ? (uint32_t)b1 : M.a; M.b = me ? (uint32_t)(b1 >> 32) : M.b; M.h = me ? b2 : M.h;
-        chi = fmaxf(chi, fmaxf(in1 ? z1 : qnan, in2 ? z2 : qnan));
+        const bool me = lane == gr;                                    // into the row's lane (two selects)
+        M.a = me ? (uint32_t)b1 : M.a; M.b = me ? (uint32_t)(b1 >> 32) : M.b;
+        chi = zmax(chi, in1 ? z1 : qnan);
+      }
+#pragma unroll
+      for (int j = 0; j < HL; j++) {                                   // the halo columns, in the row's own lane
+        const bool in2 = ((Mrem.h >> (28 + j)) & 1u) & !(zh[j] - lo > th);
+        M.h |= in2 ? (1u << (28 + j)) : 0u;
+        chi = zmax(chi, in2 ? zh[j] : qnan);
       }
       hi = wave_fmax(chi);
       Mrem = andn(Mrem, M);
@@ -880,11 +909,14 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
     const int rcol = fa ? __builtin_ctz(fa) : 32 + __builtin_ctz(fb);
     const int rootg = (y0 + rr - HL) * W + x0 + rcol;                  // the component's first tile pixel in raster order
     if (lane == rr) { if (rcol < 32) rootA |= 1u << rcol; else rootB |= 1u << (rcol - 32); }
+    int *pplane = a.parent + fN;
+    uint32_t po = 4u * (uint32_t)(y0 * W + x0 + lane);                  // this lane's pixel in the tile's first row
+    asm volatile("" : "+v"(po));                                       // (computed here, per component: not 16 row offsets held across the loop)
 #pragma unroll
     for (int j = 0; j < TH; j++) {
       const uint64_t bitsj = lane_bits(S.a, S.b, HL + j);
       if (bitsj != 0ull && __builtin_amdgcn_inverse_ballot_w64(bitsj))
-        *(int *)((char *)(a.parent + fN + (size_t)(y0 + j) * W + x0) + 4u * (uint32_t)lane) = rootg;
+        sto<int>(pplane, po + 4u * (uint32_t)(j * W), rootg);
     }
     {
       const int cnt = il ? __popc(S.a) + __popc(S.b) : 0;
@@ -893,7 +925,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
       if (il && (ka | kb)) key = (uint32_t)((y0 + lane - HL) * W + x0 + (ka ? __builtin_ctz(ka) : 32 + __builtin_ctz(kb)));
       const int size = wave_sum_lo32(cnt);
       key = wave_min_u32(key);
-      if (lane == 0) { a.rsize[fN + rootg] = size; a.rkey[fN + rootg] = (int)key; }
+      if (lane == 0) { sto<int>(a.rsize + fN, 4u * (uint32_t)rootg, size); sto<int>(a.rkey + fN, 4u * (uint32_t)rootg, (int)key); }
     }
     // halo cells of the component belong to other tiles: one link request (halo cell, root) per group of halo cells that are
     // direct neighbours (a cell whose left or upper neighbour is a halo cell of the set leaves it to that neighbour: the edge
@@ -931,7 +963,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
       todo &= todo - 1ull;
       if (__builtin_amdgcn_inverse_ballot_w64(lane_bits(Za, Zb, l))) {
         const int p = (y0 + l - HL) * W + x0 + lane;
-        a.parent[fN + p] = p; a.rsize[fN + p] = 1; a.rkey[fN + p] = kKeyNone;
+        sto<int>(a.parent + fN, 4u * (uint32_t)p, p); sto<int>(a.rsize + fN, 4u * (uint32_t)p, 1); sto<int>(a.rkey + fN, 4u * (uint32_t)p, kKeyNone);
       }
     }
   }
