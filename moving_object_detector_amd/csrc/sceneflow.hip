@@ -200,10 +200,16 @@ template <class T> __device__ __forceinline__ void st(void *base, uint32_t byte_
 // arithmetic: with them the kernel wants more than the 102 SGPRs a wave has and spills into VGPR lanes (v_writelane / v_readlane
 // pairs, which take VALU issue slots of a VALU-co-limited kernel).  Read through the kernarg segment pointer: taking the address of
 // a by-value parameter would make the compiler copy it to scratch.
-// Plane stores are plain stores (streaming stores per plane were measured: no effect beyond the process-to-process spread,
-// profiles/README.md round 3).
+// Plane stores are WRITE-THROUGH streaming stores (`sc0 sc1 nt`): a step writes 11 GB of planes that nobody on this GPU reads
+// before 20 GB of other traffic has passed, so a line kept dirty in the XCD's L2 only waits for its eviction — written through, it
+// leaves as it is produced.  In-process A/B on one set of buffers (tools/ab_inproc.py, 512 pairs, four alternations, +-0.01 ms):
+// plain 3.712 ms, `nt sc1` 3.621, `sc0 sc1 nt` 3.606; x, y, z alone 3.673, vx, vy, vz alone 3.660; `nt` alone (round 3) and
+// non-temporal LOADS of the disparity / flow planes (+4 %) do not help.  The builtin offers `nt` only, hence the asm; the
+// instruction is the very global_store_dwordx4 (SGPR base + 32-bit lane offset) the compiler emits for st().
 __device__ __forceinline__ void st_plane(float *base, uint32_t byte_off, float a0, float a1, float a2, float a3) {
-  st(base, byte_off, make_float4(a0, a1, a2, a3));
+  typedef float sf_w4 __attribute__((ext_vector_type(4)));
+  const sf_w4 v = {a0, a1, a2, a3};
+  asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt" :: "v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 #define SF_K4 __attribute__((address_space(4)))
 template <class T> __device__ __forceinline__ T karg(size_t off) {
