@@ -51,9 +51,11 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=24, help="pairs timed on the CPU (bounded sample)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--share-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
-    ap.add_argument("--workload", default="sequence", choices=["sequence", "pairs"],
+    ap.add_argument("--workload", default="sequence", choices=["sequence", "pairs", "nominal"],
                     help="sequence: one synthetic stream (frame t's now-disparity is frame t+1's previous), sharded over the ranks "
-                         "as contiguous chunks + a one-plane disparity halo (SURVEY.md 8(e)); pairs: round 1's independent pairs")
+                         "as contiguous chunks + a one-plane disparity halo (SURVEY.md 8(e)); pairs: round 1's independent pairs; "
+                         "nominal: the same stream with SURVEY.md 8(d)'s nominal object depth (4-15 m), speed (0.5-2 m/s) and "
+                         "dt = 1/15 s, where the default uses 4-9 m, 1-2 m/s and 0.1 s (DESIGN.md section 10)")
     ap.add_argument("--no-labels", action="store_true",
                     help="do not produce the cluster-label plane (the reference renders its cluster image only for subscribers)")
     ap.add_argument("--seed", type=int, default=4, help="scene seed of the synthetic stream")
@@ -305,11 +307,12 @@ def run():
     from moving_object_detector_amd.pipeline import PLANES, Context
 
     # this rank's share of the stream, tiled to F frames at distinct HBM addresses
-    if args.workload == "sequence":
+    if args.workload in ("sequence", "nominal"):
         # one stream of `total` frames; a rank materialises its contiguous chunk + the one-plane disparity halo
         # seed 4: the stream's share of dynamic pixels (12.7 %) and its cluster mix (4-6 clusters of 3-46 k px per frame) are close
         # to round 1's pair workload (13.1 %, 4-9 clusters); seeds differ 2.7x in dynamic share
-        mk = lambda first, frames: synth.make_sequence(W, H, frames, seed=args.seed, first=first, camera=args.camera)[1]
+        kw = dict(synth.NOMINAL) if args.workload == "nominal" else {}
+        mk = lambda first, frames: synth.make_sequence(W, H, frames, seed=args.seed, first=first, camera=args.camera, **kw)[1]
         sh = mdist.local_stream(mk, total, rank, world)
         cam = synth.make_camera(W, H, args.camera)
         host = {"disparity_now": sh["disparity_now"], "disparity_prev": sh["disparity_prev"], "flow": sh["flow"],
@@ -445,6 +448,7 @@ def run():
                        "frames_per_step_per_gpu": F, "distinct_frames_per_gpu": G,
                        "outputs": "six cloud planes, dynamic mask, objects" + ("" if args.no_labels else ", cluster-label plane"),
                        "stream": ("one synthetic stream, contiguous chunk per rank + one disparity plane of halo" if args.workload == "sequence"
+                                  else "the same with SURVEY.md 8(d)'s nominal object depth 4-15 m, speed 0.5-2 m/s, dt 1/15 s" if args.workload == "nominal"
                                   else "independent synthetic pairs per rank"),
                        "sharding": f"frames x{world}",
                        "collective": ("one broadcast of the intrinsics/params block before the timed region + one all-reduce (MAX) of the elapsed time"

@@ -277,7 +277,7 @@ def _tri(k: float, period: int) -> float:
 class _Scene:
     """World of one stream: wall + ground + moving boxes, all a function of (seed, size) only.  World = camera frame 0."""
 
-    def __init__(self, cam: Camera, seed: int, n_objects: int, n_small: int):
+    def __init__(self, cam: Camera, seed: int, n_objects: int, n_small: int, depth=(4.0, 9.0), speed=(1.0, 2.0)):
         self.cam = cam
         W, H = cam.width, cam.height
         rng = np.random.Generator(np.random.PCG64([0x5EED1000 + seed, 0, 2]))
@@ -291,12 +291,12 @@ class _Scene:
             else:
                 bw, bh = int(rng.integers(90, 261) * sc), int(rng.integers(120, 401) * sc)
             bw, bh = max(bw, 3), max(bh, 3)
-            zc = rng.uniform(4.0, 9.0)
+            zc = rng.uniform(depth[0], depth[1])
             x0 = int(rng.integers(8, max(9, W - bw - 8)))
             y0 = int(rng.integers(8, max(9, H - bh - 8)))
-            speed = rng.uniform(1.0, 2.0)
+            spd = rng.uniform(speed[0], speed[1])
             ang = rng.uniform(0, 2 * np.pi)
-            v = np.array([speed * np.cos(ang), 0.15 * speed * rng.uniform(-1, 1), 0.5 * speed * np.sin(ang)])
+            v = np.array([spd * np.cos(ang), 0.15 * spd * rng.uniform(-1, 1), 0.5 * spd * np.sin(ang)])
             slant = rng.uniform(-0.3, 0.3)                 # depth change across the box [m]
             # metric size and centre RELATIVE TO THE CAMERA (the boxes ride along with the vehicle, like traffic ahead of it)
             wm, hm = bw * zc / cam.fx, bh * zc / cam.fy
@@ -336,8 +336,12 @@ def _render(scene: _Scene, A: np.ndarray, b: np.ndarray, k: int, dt: float, xs, 
     return z, obj
 
 
+NOMINAL = {"depth": (4.0, 15.0), "speed": (0.5, 2.0), "dt": 1.0 / 15.0}   # SURVEY.md section 8(d)'s nominal values
+
+
 def make_sequence(width: int, height: int, frames: int, seed: int = 0, first: int = 0, *, n_objects: int = 6, n_small: int = 2,
-                  n_isolated: int = 24, dt: float = 0.1, quantize: bool = True, invalid: bool = True, camera: str = "zed"):
+                  n_isolated: int = 24, dt: float = 0.1, quantize: bool = True, invalid: bool = True, camera: str = "zed",
+                  depth=(4.0, 9.0), speed=(1.0, 2.0)):
     """A stream as the reference's stereoCallback sees it (scene_flow_constructor.cpp:364-399): disparity planes D[first ..
     first + frames] (frames + 1 planes: frame t pairs previous = D[t] with now = D[t + 1], as `disparity_previous_ =
     disparity_now_` does, :397-398), and per frame t the flow at the now pixel, the previous->now transform and dt.
@@ -348,7 +352,7 @@ def make_sequence(width: int, height: int, frames: int, seed: int = 0, first: in
     """
     cam = make_camera(width, height, camera)
     W, H = width, height
-    scene = _Scene(cam, seed, n_objects, n_small)
+    scene = _Scene(cam, seed, n_objects, n_small, depth, speed)
     f, base = float(cam.disp_f), float(cam.disp_T)
     ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
     # pose of camera index i (plane D[i]): P_i = A_i P_world + b_i, chained from index 0

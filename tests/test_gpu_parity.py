@@ -162,3 +162,19 @@ def test_kitti_style_camera_1280x720_sequence(oracle):
     assert sum(len(o) for o in out["objects"]) > 0
     for f in range(3):
         assert bits_equal(out["depth"][f], oracle.depth_image(cam, batch["disparity_now"][f]))
+
+
+def test_nominal_workload_1280x720_sequence(oracle):
+    """SURVEY.md section 8(d)'s NOMINAL synthetic workload (object depth 4-15 m, speed 0.5-2 m/s, dt = 1/15 s; the default stream uses
+    4-9 m, 1-2 m/s, 0.1 s so that more objects pass the reference's 5 px residual test — DESIGN.md section 10): three frames at
+    1280x720, reference default parameters, bit for bit against the oracle (`bench.py --workload nominal` times this stream)."""
+    from moving_object_detector_amd import synth
+    cam, seq = synth.make_sequence(1280, 720, 3, seed=4, **synth.NOMINAL)
+    batch = {"disparity_now": seq["disparity"][1:], "disparity_prev": seq["disparity"][:-1], "flow": seq["flow"],
+             "t": seq["t"], "q": seq["q"], "dt": seq["dt"]}
+    batch = {k: np.ascontiguousarray(v) for k, v in batch.items()}
+    assert float(batch["dt"][0]) == 1.0 / 15.0
+    prm = synth.Params()
+    out = _run_gpu(cam, prm, batch)
+    _check_against_oracle(oracle, cam, prm, batch, out)
+    assert sum(len(o) for o in out["objects"]) >= 6
