@@ -719,7 +719,9 @@ __device__ __forceinline__ uint64_t lane_bits(uint32_t lo, uint32_t hi, int l) {
   return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, l) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)lo, l);
 }
 
-constexpr int kTilesPerBlock = 4, kMaxClasses = 4;
+// one tile (= one wave) per workgroup: 1 / 2 / 4 / 8 tiles per workgroup measured 0.451 / 0.455 / 0.521 / 0.642 ms per 512 pairs
+// (in-process A/B): a workgroup's slot and LDS stay occupied until its slowest wave is done, and three quarters of the tiles are empty
+constexpr int kTilesPerBlock = 1, kMaxClasses = 4;
 
 // Global accesses of this kernel: ONE wave-uniform base per plane (frame's plane, in SGPRs) + a 32-bit byte offset per lane — the
 // `global_load / global_store v, v_off, s[base]` form.  (A frame's planes span less than 2^29 bytes: mod_create caps W * H at 2^27.)
@@ -1868,6 +1870,7 @@ void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
     // listed — resident workgroups (8 per CU) that pull tiles with an atomic cursor
     const dim3 bgrid((tgrid.x + bits::kTilesPerBlock - 1) / bits::kTilesPerBlock, tgrid.y, tgrid.z);
     hipLaunchKernelGGL(bits::k_ccl_bits, bgrid, dim3(64, bits::kTilesPerBlock, 1), 0, s, c, a, tx, tyn);
+    // (2048 workgroups = the 8 per CU that fit: 512 / 1024 / 4096 / 8192 measured slower or equal)
     const unsigned total = tgrid.x * tgrid.y * tgrid.z;
     hipLaunchKernelGGL((k_ccl_tile_list<kTileH, 4, kTileWaves, true>), dim3(std::min(2048u, total)), block, 0, s, c, a, tx, tyn);
     return;
