@@ -36,7 +36,7 @@ for k, d in per.items():
 json.dump(traffic, open(f"profiles/{tag.split('_')[0]}_traffic.json", "w"), indent=1)
 # extra bench lines + SQ counters (64-frame dispatches) of the two main kernels
 extra = {}
-for name in ("pairs", "64", "kitti"):
+for name in ("pairs", "64", "kitti", "nominal"):
     try:
         j = json.loads(open(f"{src}/bench_{name}.json").read().strip().splitlines()[-1])
         extra[name] = {"value": j["value"], "ms_per_step": j["ms_per_step"], "frames_per_step": j["config"]["frames_per_step_per_gpu"],
@@ -49,7 +49,7 @@ for d in sorted(glob.glob(f"{src}/pmc_sq*")):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for fcsv in glob.glob(f"{d}/*/*counter_collection.csv"):
         for r in csv.DictReader(open(fcsv)):
-            m = re.search(r"(k_scene_flow\w*|k_ccl_tile|k_final|k_median\b|k_ccl_link)", r["Kernel_Name"])
+            m = re.search(r"(k_scene_flow\w*|k_ccl_bits|k_ccl_tile_list|k_ccl_tile|k_final|k_median\b|k_ccl_link)", r["Kernel_Name"])
             if m: agg[(m.group(1), r["Counter_Name"])][0] += 1; agg[(m.group(1), r["Counter_Name"])][1] += float(r["Counter_Value"])
     for (k, cn), (n, v) in agg.items(): sq[k][cn] = v / n
 json.dump({"other_bench_lines": extra, "sq_counters_per_64_frame_dispatch": sq}, open(f"profiles/{tag}_extra.json", "w"), indent=1)

@@ -1,6 +1,6 @@
 # Produces the round's committed evidence under gpurun_out/final/: bench JSON (with cpu baseline), rocprofv3 kernel stats of
 # the same command, FETCH_SIZE / WRITE_SIZE passes, SQ instruction counters of the two main kernels, a 64-pair and a pairs-workload line.
-# Run on the GPU box from the repo root: bash tools/round_profile.sh ; then (anywhere) python tools/collect_profiles.py r03_final
+# Run on the GPU box from the repo root: bash tools/round_profile.sh ; then (anywhere) python tools/collect_profiles.py r04_final
 # (the profiled commands skip bench.py's config-5 leg: its small scene-flow launches would dilute the per-launch averages)
 out=$PWD/gpurun_out/final
 rm -rf $out; mkdir -p $out
@@ -9,6 +9,7 @@ echo "bench rc=$?"
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --workload pairs > $out/bench_pairs.json 2> $out/bench_pairs.err
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --frames 64 > $out/bench_64.json 2> $out/bench_64.err
 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --camera kitti > $out/bench_kitti.json 2> $out/bench_kitti.err
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --workload nominal > $out/bench_nominal.json 2> $out/bench_nominal.err
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $repo/bench.py --no-cpu-baseline --no-config5 > $out/stats_bench.json 2> $out/stats.err
