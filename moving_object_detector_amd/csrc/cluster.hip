@@ -1493,8 +1493,9 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
       o->velocity[0] = (double)bvx; o->velocity[1] = (double)bvy; o->velocity[2] = (double)bvz;
       // bbox / centre (cluster2MovingObject, clusterer_nodelet.cpp:151-161): F32 max-min and (min+max)/2, widened to F64
+      // (getMinMax3D starts from +-FLT_MAX: members at +inf leave the minimum there, members at -inf the maximum)
       for (int d = 0; d < 3; d++) {
-        const float mn = ord2f(rec.w[d]), mx = ord2f(~rec.w[3 + d]);
+        const float mn = fminf(ord2f(rec.w[d]), 3.402823466e38f), mx = fmaxf(ord2f(~rec.w[3 + d]), -3.402823466e38f);
         o->bounding_box[d] = (double)(mx - mn);
         o->center[d] = (double)((mn + mx) / 2.0f);
       }
@@ -1527,7 +1528,8 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
           if (tid == 0) {
             ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
             const float nanv = __uint_as_float(0x7fc00000u);
-            const float mn = s_val ? ord2f(s_bin) : nanv, mx = s_val ? ord2f(s_rem) : nanv;
+            float mn = s_val ? ord2f(s_bin) : nanv, mx = s_val ? ord2f(s_rem) : nanv;
+            if (lastnan == 0u) { mn = fminf(mn, 3.402823466e38f); mx = fmaxf(mx, -3.402823466e38f); }   // no NaN in this coordinate: the +-FLT_MAX start values hold
             o->bounding_box[d] = (double)(mx - mn);
             o->center[d] = (double)((mn + mx) / 2.0f);
           }
