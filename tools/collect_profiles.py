@@ -47,7 +47,7 @@ sq = collections.defaultdict(dict)
 for d in sorted(glob.glob(f"{src}/pmc_sq*")):
     if not os.path.isdir(d): continue
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for fcsv in glob.glob(f"{d}/*/*counter_collection.csv"):
+    for fcsv in [max(glob.glob(f"{d}/*/*counter_collection.csv"), key=os.path.getmtime)]:   # newest run only (gpurun merges into old directories)
         for r in csv.DictReader(open(fcsv)):
             m = re.search(r"(k_scene_flow\w*|k_ccl_bits|k_ccl_tile_list|k_ccl_tile|k_final|k_median\b|k_ccl_link)", r["Kernel_Name"])
             if m: agg[(m.group(1), r["Counter_Name"])][0] += 1; agg[(m.group(1), r["Counter_Name"])][1] += float(r["Counter_Value"])
@@ -67,7 +67,7 @@ try:
         m = re.search(r"(k_sgm_\w+(<[^>]*>)?)", r["Name"])
         if m: sgm["kernels_avg_us"][m.group(1)] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "percent": float(r["Percentage"])}
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for fcsv in glob.glob(f"{src}/sgm_pmc/*/*counter_collection.csv"):
+    for fcsv in [max(glob.glob(f"{src}/sgm_pmc/*/*counter_collection.csv"), key=os.path.getmtime)]:
         for r in csv.DictReader(open(fcsv)):
             m = re.search(r"(k_sgm_\w+(<[^>]*>)?)", r["Kernel_Name"])
             if m: agg[(m.group(1), r["Counter_Name"])][0] += 1; agg[(m.group(1), r["Counter_Name"])][1] += float(r["Counter_Value"])
