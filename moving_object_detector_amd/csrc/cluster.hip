@@ -651,34 +651,60 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 // ~700 wave-instructions per such tile against ~17 000 of the union-find kernel.  Tiles that fail the depth test go to a list for
 // k_ccl_tile_list.  Model of the bit algorithm against brute force: tests/models/ccl_bits_model.py.
 namespace bits {
-constexpr int TH = 16, HL = 4, PH = TH + HL;
+constexpr int TH = 16;
 
-struct Row3 { uint32_t h, a, b; };   // columns x0-4 .. x0-1 at bits 28..31 of h, x0 .. x0+31 in a, x0+32 .. x0+63 in b
+struct Row3 { uint32_t h, a, b; };   // the n halo columns x0-n .. x0-1 in the top n bits of h, x0 .. x0+31 in a, x0+32 .. x0+63 in b
 
 __device__ __forceinline__ Row3 operator|(Row3 x, Row3 y) { return {x.h | y.h, x.a | y.a, x.b | y.b}; }
 __device__ __forceinline__ Row3 operator&(Row3 x, Row3 y) { return {x.h & y.h, x.a & y.a, x.b & y.b}; }
 __device__ __forceinline__ Row3 operator^(Row3 x, Row3 y) { return {x.h ^ y.h, x.a ^ y.a, x.b ^ y.b}; }
 __device__ __forceinline__ Row3 andn(Row3 x, Row3 y) { return {x.h & ~y.h, x.a & ~y.a, x.b & ~y.b}; }
 __device__ __forceinline__ bool any(Row3 x) { return (x.h | x.a | x.b) != 0u; }
+// Shifts by K >= 1 columns.  NH = number of halo columns (= neighbor_distance): they sit in the top NH bits of h.
 template <int K> __device__ __forceinline__ Row3 shl(Row3 v) {      // towards larger x
   return {v.h << K, __builtin_amdgcn_alignbit(v.a, v.h, 32 - K), __builtin_amdgcn_alignbit(v.b, v.a, 32 - K)};
 }
-template <int K> __device__ __forceinline__ Row3 shr(Row3 v) {      // towards smaller x; cells left of column x0 - 4 do not exist
-  return {__builtin_amdgcn_alignbit(v.a, v.h, K) & 0xF0000000u, __builtin_amdgcn_alignbit(v.b, v.a, K), v.b >> K};
+template <int K, int NH> __device__ __forceinline__ Row3 shr(Row3 v) {      // towards smaller x; cells left of column x0 - NH do not exist
+  return {__builtin_amdgcn_alignbit(v.a, v.h, K) & (~0u << (32 - NH)), __builtin_amdgcn_alignbit(v.b, v.a, K), v.b >> K};
 }
-// v | v << 1 | .. | v << 4 by doubling; x: the same without v itself
-__device__ __forceinline__ void dil_r(Row3 v, Row3 &all, Row3 &x) { Row3 y = v | shl<1>(v); y = y | shl<2>(y); x = shl<1>(y); all = v | x; }
-__device__ __forceinline__ void dil_l(Row3 v, Row3 &all, Row3 &x) { Row3 y = v | shr<1>(v); y = y | shr<2>(y); x = shr<1>(y); all = v | x; }
 // the row above / below arrives (zero into the first / last lane).  All 64 lanes must be active.
 __device__ __forceinline__ uint32_t dn1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false); }   // wave_shr:1
 __device__ __forceinline__ uint32_t up1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false); }   // wave_shl:1
 __device__ __forceinline__ Row3 row_dn(Row3 v) { return {dn1(v.h), dn1(v.a), dn1(v.b)}; }
 __device__ __forceinline__ Row3 row_up(Row3 v) { return {up1(v.h), up1(v.a), up1(v.b)}; }
-// OR over dv = 1 .. 4 of the rows dv above (DN) / below, by doubling
-template <bool DN> __device__ __forceinline__ Row3 vert4(Row3 v) {
-  if (DN) { const Row3 t1 = v | row_dn(v); const Row3 t2 = t1 | row_dn(row_dn(t1)); return row_dn(t2); }
-  const Row3 t1 = v | row_up(v); const Row3 t2 = t1 | row_up(row_up(t1)); return row_up(t2);
+template <int K, bool DN> __device__ __forceinline__ Row3 row_shift(Row3 v) {   // K rows
+  if constexpr (K == 0) return v;
+  else return row_shift<K - 1, DN>(DN ? row_dn(v) : row_up(v));
 }
+// OR of v shifted by 0 .. N - 1 (columns: DIR 0 right, 1 left; rows: DIR 2 down, 3 up) by doubling: a set that covers shifts
+// 0 .. COV is ORed with itself shifted by min(COV + 1, rest).  N = 4: two steps (1, 2); N = 10: four (1, 2, 4, 2).
+template <int COV, int N, int DIR> __device__ __forceinline__ Row3 grow(Row3 y) {
+  if constexpr (COV >= N - 1) return y;
+  else {
+    constexpr int S = (COV + 1 < N - 1 - COV) ? COV + 1 : N - 1 - COV;
+    Row3 t;
+    if constexpr (DIR == 0) t = shl<S>(y);
+    else if constexpr (DIR == 1) t = shr<S, N>(y);
+    else t = row_shift<S, DIR == 2>(y);
+    return grow<COV + S, N, DIR>(y | t);
+  }
+}
+// v | v << 1 | .. | v << N; x: the same without v itself
+template <int N> __device__ __forceinline__ void dil_r(Row3 v, Row3 &all, Row3 &x) { x = shl<1>(grow<0, N, 0>(v)); all = v | x; }
+template <int N> __device__ __forceinline__ void dil_l(Row3 v, Row3 &all, Row3 &x) { x = shr<1, N>(grow<0, N, 1>(v)); all = v | x; }
+// OR over dv = 1 .. N of the rows dv above (DN) / below
+template <int N, bool DN> __device__ __forceinline__ Row3 vert(Row3 v) { return row_shift<1, DN>(grow<0, N, DN ? 2 : 3>(v)); }
+// M with the gaps of <= N - 1 cells between two dynamic cells closed: a cell is in the result iff a dynamic cell lies i to its left
+// and one j to its right with i + j <= N (cells of one run of the result are chained by same-row links)
+template <int I, int N> __device__ __forceinline__ Row3 closed_rec(Row3 M, Row3 lprev) {   // term I: (dynamic within I to the left) & (dynamic N - I to the right)
+  Row3 l, r;
+  if constexpr (I == 0) l = M; else l = lprev | shl<I>(M);
+  if constexpr (I == N) r = M; else r = shr<N - I, N>(M);
+  const Row3 t = l & r;
+  if constexpr (I == N) return t;
+  else return t | closed_rec<I + 1, N>(M, l);
+}
+template <int N> __device__ __forceinline__ Row3 closed(Row3 M) { return closed_rec<0, N>(M, M); }
 __device__ __forceinline__ Row3 rev(Row3 v) { return {__builtin_bitreverse32(v.b), __builtin_bitreverse32(v.a), __builtin_bitreverse32(v.h)}; }
 // all bits of the runs of c that hold a bit of s (s subset of c), from the lowest such bit upwards: c + s ripples through a run
 __device__ __forceinline__ Row3 fill_up(Row3 c, Row3 s) {
@@ -710,7 +736,7 @@ __device__ __forceinline__ float wave_fmax(float v) {
   const float a = lane_f32(v, 0), b = lane_f32(v, 16), c = lane_f32(v, 32), d = lane_f32(v, 48);
   return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
-// sum over lanes 0 .. 31 (the grid rows live in lanes 0 .. 19)
+// sum over lanes 0 .. 31 (the grid rows live in lanes 0 .. 15 + neighbor_distance)
 __device__ __forceinline__ int wave_sum_lo32(int v) {
   v += (int)MOD_DPP(v, 0xB1); v += (int)MOD_DPP(v, 0x4E); v += (int)MOD_DPP(v, 0x141); v += (int)MOD_DPP(v, 0x140);
   return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16);
@@ -721,7 +747,7 @@ __device__ __forceinline__ uint64_t lane_bits(uint32_t lo, uint32_t hi, int l) {
 
 // one tile (= one wave) per workgroup: 1 / 2 / 4 / 8 tiles per workgroup measured 0.451 / 0.455 / 0.521 / 0.642 ms per 512 pairs
 // (in-process A/B): a workgroup's slot and LDS stay occupied until its slowest wave is done, and three quarters of the tiles are empty
-constexpr int kTilesPerBlock = 1, kMaxClasses = 4;
+constexpr int kTilesPerBlock = 1, kMaxClasses = 4, kMaxComps = 32;
 
 // Global accesses of this kernel: ONE wave-uniform base per plane (frame's plane, in SGPRs) + a 32-bit byte offset per lane — the
 // `global_load / global_store v, v_off, s[base]` form.  (A frame's planes span less than 2^29 bytes: mod_create caps W * H at 2^27.)
@@ -730,7 +756,9 @@ constexpr int kTilesPerBlock = 1, kMaxClasses = 4;
 template <class T> __device__ __forceinline__ T ldo(const void *base, uint32_t byte_off) { return *(const T *)((const char *)base + byte_off); }
 template <class T> __device__ __forceinline__ void sto(void *base, uint32_t byte_off, T v) { *(T *)((char *)base + byte_off) = v; }
 
+template <int HL>                                                     // HL = neighbor_distance = halo rows above = halo columns left
 __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClArgs a, int tiles_x, int tiles_y) {
+  constexpr int PH = TH + HL;                                          // grid rows = lanes in use
   const int lane = threadIdx.x, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.y);
   const int wi = blockIdx.x * kTilesPerBlock + wv, ty = blockIdx.y, f = blockIdx.z;
   if (wi >= tiles_x) return;
@@ -746,7 +774,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
     const bool inrow = lane < PH && gy >= 0 && gy < H;
     const uint64_t *mr = a.mask + ((size_t)f * H + (inrow ? gy : 0)) * MW;
     const uint64_t q0 = mr[wi], qL = mr[max(wi - 1, 0)];              // unconditional loads, clamped addresses
-    Mrem.h = (inrow && wi > 0) ? ((uint32_t)(qL >> 32) & 0xF0000000u) : 0u;
+    Mrem.h = (inrow && wi > 0) ? ((uint32_t)(qL >> 32) & (~0u << (32 - HL))) : 0u;
     Mrem.a = inrow ? (uint32_t)q0 : 0u;
     Mrem.b = inrow ? (uint32_t)(q0 >> 32) : 0u;
   }
@@ -755,7 +783,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
   // (uniform row base + 32-bit lane offset: the `global_load v, v_off, s[base]` form, no 64-bit address arithmetic per lane)
   const uint32_t oc = 4u * (uint32_t)min(x0 + lane, W - 1);
   uint32_t rootA = 0u, rootB = 0u;                                     // root bits of the tile rows (lane = row)
-  int nreq = 0;
+  int nreq = 0, ncomp = 0;
   uint2 *req = a.requests + tix * a.req_cap;
   float hi_prev = 0.0f;
   bool bail = false;
@@ -782,7 +810,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
   float lo = qnan, hi = qnan;
   {
     uint64_t nanb = 0ull;
-    constexpr int HB = PH / 2;                                         // two batches of 10 rows
+    constexpr int HB = (PH + 1) / 2;                                   // two batches of rows (10 + 10 at HL = 4)
 #pragma unroll
     for (int g0 = 0; g0 < PH; g0 += HB) {
       float zr[HB];
@@ -794,6 +822,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
 #pragma unroll
       for (int i = 0; i < HB; i++) {
         const int gr = g0 + i;
+        if (gr >= PH) break;
         const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
         const float z1 = dyn ? zr[i] : qnan;
         lo = zmin(lo, z1); hi = zmax(hi, z1);
@@ -804,7 +833,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
     }
 #pragma unroll
     for (int j = 0; j < HL; j++) {
-      const bool hd = (Mrem.h >> (28 + j)) & 1u;
+      const bool hd = (Mrem.h >> (32 - HL + j)) & 1u;
       const float z2 = hd ? zh[j] : qnan;
       lo = zmin(lo, z2); hi = zmax(hi, z2);
       if (!a.xy_from_z) nanb |= __ballot(hd & (zh[j] != zh[j]));
@@ -818,7 +847,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
     if (pass == kMaxClasses) { bail = true; break; }
     if (pass > 0) {                                                    // smallest / largest depth of what is left
       lo = qnan; hi = qnan;
-#pragma unroll 5
+#pragma unroll 4
       for (int gr = 0; gr < PH; gr++) {
         const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
         const float z1 = dyn ? zl[gr][lane] : qnan;
@@ -826,7 +855,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
       }
 #pragma unroll
       for (int j = 0; j < HL; j++) {
-        const float z2 = ((Mrem.h >> (28 + j)) & 1u) ? zh[j] : qnan;
+        const float z2 = ((Mrem.h >> (32 - HL + j)) & 1u) ? zh[j] : qnan;
         lo = zmin(lo, z2); hi = zmax(hi, z2);
       }
     }
@@ -836,7 +865,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
     else {
       M = {0u, 0u, 0u};
       float chi = qnan;
-#pragma unroll 5
+#pragma unroll 4
       for (int gr = 0; gr < PH; gr++) {
         const bool dyn = __builtin_amdgcn_inverse_ballot_w64(lane_bits(Mrem.a, Mrem.b, gr));
         const float z1 = zl[gr][lane];
@@ -848,8 +877,8 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
       }
 #pragma unroll
       for (int j = 0; j < HL; j++) {                                   // the halo columns, in the row's own lane
-        const bool in2 = ((Mrem.h >> (28 + j)) & 1u) & !(zh[j] - lo > th);
-        M.h |= in2 ? (1u << (28 + j)) : 0u;
+        const bool in2 = ((Mrem.h >> (32 - HL + j)) & 1u) & !(zh[j] - lo > th);
+        M.h |= in2 ? (1u << (32 - HL + j)) : 0u;
         chi = zmax(chi, in2 ? zh[j] : qnan);
       }
       hi = wave_fmax(chi);
@@ -859,16 +888,12 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
     hi_prev = hi;
   // ---- per-row facts ---------------------------------------------------------------------------------------------------------------
   Row3 drA, drX, dlA, dlX;
-  dil_r(M, drA, drX);
-  dil_l(M, dlA, dlX);
-  const Row3 above = vert4<true>(drA);                                 // cells that have a dynamic cell up-left in one of the 4 rows above
+  dil_r<HL>(M, drA, drX);
+  dil_l<HL>(M, dlA, dlX);
+  const Row3 above = vert<HL, true>(drA);                              // cells that have a dynamic cell up-left in one of the HL rows above
   const Row3 UL = M & (drX | above);                                   // has an up-left edge
-  const Row3 E = UL | (M & (dlX | vert4<false>(dlA)));                 // has any edge
-  Row3 C;                                                              // M with gaps of <= 3 cells closed: one run = one chain of same-row links
-  {
-    const Row3 l1 = M | shl<1>(M), l2 = l1 | shl<2>(M), l3 = l2 | shl<3>(M), l4 = l3 | shl<4>(M);
-    C = (l4 & M) | (l3 & shr<1>(M)) | (l2 & shr<2>(M)) | (l1 & shr<3>(M)) | (M & shr<4>(M));
-  }
+  const Row3 E = UL | (M & (dlX | vert<HL, false>(dlA)));              // has any edge
+  const Row3 C = closed<HL>(M);                                        // M with gaps of < HL cells closed: one run = one chain of same-row links
   const Row3 rC = rev(C);
   Row3 R = {0u, il ? (M.a & E.a) : 0u, il ? (M.b & E.b) : 0u};         // tile pixels with an edge that no component holds yet
   const uint32_t Za = il ? (M.a & ~E.a) : 0u, Zb = il ? (M.b & ~E.b) : 0u;   // tile pixels without any edge: roots of their own
@@ -895,9 +920,9 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
       S = {0u, lane == sr ? ba : 0u, lane == sr ? bb : 0u};
       for (;;) {                                                       // flood: S only grows, inside M
         Row3 rA, rX, lA, lX;
-        dil_r(S, rA, rX);
-        dil_l(S, lA, lX);
-        const Row3 reach = M & (rA | lA | vert4<true>(rA) | vert4<false>(lA));
+        dil_r<HL>(S, rA, rX);
+        dil_l<HL>(S, lA, lX);
+        const Row3 reach = M & (rA | lA | vert<HL, true>(rA) | vert<HL, false>(lA));
         const Row3 S2 = (fill_up(C, reach) | rev(fill_up(rC, rev(reach)))) & M;
         const bool grew = any(S2 ^ S);
         S = S2;
@@ -940,9 +965,9 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
         const int l = __builtin_ctzll(todo);
         todo &= todo - 1ull;
         const uint64_t eb = lane_bits(em.a, em.b, l);
-        const uint32_t eh = (uint32_t)__builtin_amdgcn_readlane((int)em.h, l) >> 28;
+        const uint32_t eh = (uint32_t)__builtin_amdgcn_readlane((int)em.h, l) >> (32 - HL);
         const int hgrow = (y0 - HL + l) * W + x0;
-        if (__builtin_amdgcn_inverse_ballot_w64((uint64_t)eh)) {       // left-halo columns x0 - 4 + lane, lanes 0 .. 3
+        if (__builtin_amdgcn_inverse_ballot_w64((uint64_t)eh)) {       // left-halo columns x0 - HL + lane, lanes 0 .. HL - 1
           const int slot = nreq + __popc(eh & ((1u << lane) - 1u));
           if (MOD_CHECK(a, slot < a.req_cap, 12)) req[slot] = make_uint2((uint32_t)(hgrow - HL + lane), (uint32_t)rootg);
         }
@@ -956,6 +981,9 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
     }
     if (single) break;
     R = andn(R, S);
+    // a tile in dozens of pieces (noise at a small window) is flooded piece by piece: beyond kMaxComps the union-find kernel,
+    // which takes them all at once, is the cheaper one
+    if (++ncomp >= kMaxComps && __ballot(any(R)) != 0ull) { bail = true; break; }
   }
   // ---- tile pixels without any edge: each its own root with an empty key (the reference never labels them) ----
   {
@@ -969,7 +997,7 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
       }
     }
   }
-    if (__ballot(any(Mrem)) == 0ull) break;                            // wave-uniform: every dynamic cell is in a class
+    if (bail || __ballot(any(Mrem)) == 0ull) break;                    // wave-uniform: every dynamic cell is in a class
   }
   if (bail) {                                                          // wave-uniform: leave the tile to the union-find kernel, which
     if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;   // rewrites whatever classes published before the bail
@@ -1867,14 +1895,23 @@ static dim3 tile_grid(const DevCam &c, int frames) { return dim3(c.mask_words, (
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   const dim3 block(64, kTileWaves, 1), tgrid = tile_grid(c, frames);
   const int tx = (int)tgrid.x, tyn = (int)tgrid.y;
-  if (c.n == 4) {
-    // the reference's default window: bit-plane kernel first (one wave per tile), then the union-find kernel over the tiles it
-    // listed — resident workgroups (8 per CU) that pull tiles with an atomic cursor
-    const dim3 bgrid((tgrid.x + bits::kTilesPerBlock - 1) / bits::kTilesPerBlock, tgrid.y, tgrid.z);
-    hipLaunchKernelGGL(bits::k_ccl_bits, bgrid, dim3(64, bits::kTilesPerBlock, 1), 0, s, c, a, tx, tyn);
+  if (c.n >= 1 && c.n <= 10) {
+    // the reference's parameter range (Clusterer.cfg:11): bit-plane kernel first (one wave per tile, one instance per window size),
+    // then the union-find kernel over the tiles it listed — resident workgroups (8 per CU) that pull tiles with an atomic cursor
+    const dim3 bgrid((tgrid.x + bits::kTilesPerBlock - 1) / bits::kTilesPerBlock, tgrid.y, tgrid.z), bblock(64, bits::kTilesPerBlock, 1);
+    switch (c.n) {
+#define MOD_BITS_CASE(n) case n: hipLaunchKernelGGL(bits::k_ccl_bits<n>, bgrid, bblock, 0, s, c, a, tx, tyn); break;
+      MOD_BITS_CASE(1) MOD_BITS_CASE(2) MOD_BITS_CASE(3) MOD_BITS_CASE(4) MOD_BITS_CASE(5)
+      MOD_BITS_CASE(6) MOD_BITS_CASE(7) MOD_BITS_CASE(8) MOD_BITS_CASE(9) MOD_BITS_CASE(10)
+#undef MOD_BITS_CASE
+    }
     // (2048 workgroups = the 8 per CU that fit: 512 / 1024 / 4096 / 8192 measured slower or equal)
     const unsigned total = tgrid.x * tgrid.y * tgrid.z;
-    hipLaunchKernelGGL((k_ccl_tile_list<kTileH, 4, kTileWaves, true>), dim3(std::min(2048u, total)), block, 0, s, c, a, tx, tyn);
+    const dim3 lgrid(std::min(2048u, total));
+    if (c.n == 4) hipLaunchKernelGGL((k_ccl_tile_list<kTileH, 4, kTileWaves, true>), lgrid, block, 0, s, c, a, tx, tyn);
+    else if (c.n < 4) hipLaunchKernelGGL((k_ccl_tile_list<kTileH, 4, kTileWaves, false>), lgrid, block, 0, s, c, a, tx, tyn);
+    else if (c.n <= 8) hipLaunchKernelGGL((k_ccl_tile_list<kTileH, 8, kTileWaves, false>), lgrid, block, 0, s, c, a, tx, tyn);
+    else hipLaunchKernelGGL((k_ccl_tile_list<kTileH, 16, kTileWaves, false>), lgrid, block, 0, s, c, a, tx, tyn);
     return;
   }
   const dim3 ggrid((tgrid.x + CCL_TPB - 1) / CCL_TPB, tgrid.y, tgrid.z);

@@ -3,19 +3,28 @@ Python integers, word for word what the kernel does on (h, a, b) register triple
 
 A tile whose dynamic cells all pass each other's depth gate has the connectivity of its MASK alone
 (clusterer_nodelet.cpp:56-83,186-219 with `depthDiff` never firing): p ~ q iff both dynamic and q lies in p's up-left
-(n+1)x(n+1) window, n = 4.  Grid = 20 rows (4 halo rows above + 16 tile rows) x 68 columns (4 halo columns left + 64);
-a row is one 96-bit integer, column c (c = -4 .. 63) at bit c + 32.
+(n+1)x(n+1) window, n = neighbor_distance (1 .. 10; configure(n)).  Grid = n halo rows above + 16 tile rows, n halo columns left + 64;
+a row is one 96-bit integer, column c (c = -n .. 63) at bit c + 32.
 
 TEST INFRASTRUCTURE (tests/test_ccl_bits_model.py): checked against brute-force components of the same graph."""
 import random
 
-N = 4
-ROWS, TH = 20, 16
+TH = 16
 BITS = 96
 FULL = (1 << BITS) - 1
-GRID = ((1 << 68) - 1) << 28          # columns -4 .. 63
 INTERIOR = ((1 << 64) - 1) << 32      # columns 0 .. 63
-HALO_COLS = 0xF << 28
+
+
+def configure(n):
+    """neighbor_distance n: n halo rows above, n halo columns to the left (the kernel is a template on it, 1 .. 10)."""
+    global N, ROWS, GRID, HALO_COLS
+    N = n
+    ROWS = TH + n
+    GRID = ((1 << (64 + n)) - 1) << (32 - n)      # columns -n .. 63
+    HALO_COLS = ((1 << n) - 1) << (32 - n)
+
+
+configure(4)
 
 
 def shl(v, k):                        # towards larger x
@@ -26,17 +35,22 @@ def shr(v, k):                        # towards smaller x; bits left of column -
     return (v >> k) & GRID
 
 
-def dil_r(v, lo=0):                   # v | v<<1 | .. | v<<4 (lo = 1: without v itself), by doubling
-    y = v | shl(v, 1)
-    y = y | shl(y, 2)                 # 0 .. 3
-    x = shl(y, 1)                     # 1 .. 4
+def _grow(v, sh):                     # v | sh(v, 1) | .. | sh(v, N - 1) by doubling: the covered range grows by min(covered + 1, rest)
+    y, cov = v, 0
+    while cov < N - 1:
+        s = min(cov + 1, N - 1 - cov)
+        y = y | sh(y, s)
+        cov += s
+    return y
+
+
+def dil_r(v, lo=0):                   # v | v<<1 | .. | v<<N (lo = 1: without v itself)
+    x = shl(_grow(v, shl), 1)         # 1 .. N
     return x if lo else v | x
 
 
 def dil_l(v, lo=0):
-    y = v | shr(v, 1)
-    y = y | shr(y, 2)
-    x = shr(y, 1)
+    x = shr(_grow(v, shr), 1)
     return x if lo else v | x
 
 
@@ -52,11 +66,19 @@ def orr(a, b):
     return [x | y for x, y in zip(a, b)]
 
 
-def vert4(rows, dn):                  # OR over dv = 1..4 of the rows dv above (dn) / below (not dn), by doubling
-    sh = row_dn if dn else row_up
-    t1 = orr(rows, sh(rows))                      # dv 0..1
-    t2 = orr(t1, sh(sh(t1)))                      # dv 0..3
-    return sh(t2)                                 # dv 1..4
+def vert4(rows, dn):                  # OR over dv = 1..N of the rows dv above (dn) / below (not dn), by doubling
+    sh1 = row_dn if dn else row_up
+
+    def sh(r, k):
+        for _ in range(k):
+            r = sh1(r)
+        return r
+    y, cov = rows, 0
+    while cov < N - 1:
+        s = min(cov + 1, N - 1 - cov)
+        y = orr(y, sh(y, s))
+        cov += s
+    return sh1(y)                                 # dv 1..N
 
 
 def brev(v):
@@ -76,12 +98,12 @@ def closed(m):
     """m with the gaps of <= 3 cells between two dynamic cells filled: the cells of one run of the result are chained by
     same-row links (dv = 0, k <= 4).  A cell is in the result iff a dynamic cell lies i to its left and one j to its right
     with i + j <= 4."""
-    l1 = m | shl(m, 1); l2 = l1 | shl(m, 2); l3 = l2 | shl(m, 3); l4 = l3 | shl(m, 4)      # dynamic cell within i to the left
-    c = l4 & m
-    c |= l3 & shr(m, 1)
-    c |= l2 & shr(m, 2)
-    c |= l1 & shr(m, 3)
-    c |= m & shr(m, 4)
+    l = [m]                                       # l[i]: a dynamic cell within i to the left
+    for i in range(1, N + 1):
+        l.append(l[-1] | shl(m, i))
+    c = 0
+    for j in range(N + 1):
+        c |= l[N - j] & (shr(m, j) if j else m)
     return c & GRID
 
 
@@ -140,7 +162,7 @@ def tile(M, use_check=True):
     inter_rows = range(ROWS - TH, ROWS)
 
     def cells(v):
-        return [b - 32 for b in range(28, 96) if (v >> b) & 1]
+        return [b - 32 for b in range(32 - N, 96) if (v >> b) & 1]
 
     # singletons: interior cells without any edge
     for r in inter_rows:
@@ -183,7 +205,7 @@ def tile(M, use_check=True):
 
 # ---- brute force ------------------------------------------------------------------------------------------------------------
 def brute(M):
-    dyn = {(r, c) for r in range(ROWS) for c in range(-4, 64) if (M[r] >> (c + 32)) & 1}
+    dyn = {(r, c) for r in range(ROWS) for c in range(-N, 64) if (M[r] >> (c + 32)) & 1}
     par = {p: p for p in dyn}
 
     def find(p):
@@ -245,34 +267,35 @@ def random_mask(rng, kind):
     if kind == "noise":
         d = rng.choice([0.02, 0.1, 0.3, 0.6, 0.95])
         for r in range(ROWS):
-            for c in range(-4, 64):
+            for c in range(-N, 64):
                 if rng.random() < d:
                     M[r] |= 1 << (c + 32)
     elif kind in ("blobs", "oneblob"):
         for _ in range(rng.randint(1, 4) if kind == "blobs" else 1):
-            x0, x1 = sorted(rng.sample(range(-4, 64), 2)); y0, y1 = sorted(rng.sample(range(0, ROWS), 2))
+            x0, x1 = sorted(rng.sample(range(-N, 64), 2)); y0, y1 = sorted(rng.sample(range(0, ROWS), 2))
             for r in range(y0, y1 + 1):
                 for c in range(x0, x1 + 1):
                     if rng.random() < 0.94:
                         M[r] |= 1 << (c + 32)
         for _ in range(rng.randint(0, 3) if kind == "blobs" else 0):
-            M[rng.randrange(ROWS)] |= 1 << (rng.randrange(-4, 64) + 32)
+            M[rng.randrange(ROWS)] |= 1 << (rng.randrange(-N, 64) + 32)
     else:   # stripes: vertical / horizontal bars with gaps around the window size
-        gap = rng.randint(3, 6)
+        gap = rng.randint(max(N - 1, 2), N + 2)
         for r in range(ROWS):
-            for c in range(-4, 64):
-                if (kind == "vbars" and (c + 4) % gap == 0) or (kind == "hbars" and r % gap == 0):
+            for c in range(-N, 64):
+                if (kind == "vbars" and (c + N) % gap == 0) or (kind == "hbars" and r % gap == 0):
                     if rng.random() < 0.9:
                         M[r] |= 1 << (c + 32)
     if rng.random() < 0.3:
-        for r in range(4):
+        for r in range(N):
             M[r] = 0                      # image top
     if rng.random() < 0.3:
         M = [m & ~HALO_COLS for m in M]   # image left
     return M
 
 
-def run(seed, cases=150):
+def run(seed, cases=150, n=4):
+    configure(n)
     rng = random.Random(seed)
     agg = {"check": 0, "flood": 0, "sweeps": 0, "tiles": 0}
     for i in range(cases):
@@ -286,4 +309,4 @@ def run(seed, cases=150):
 
 if __name__ == "__main__":
     import sys
-    print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 300))
+    print(run(int(sys.argv[1]) if len(sys.argv) > 1 else 1, int(sys.argv[2]) if len(sys.argv) > 2 else 300, int(sys.argv[3]) if len(sys.argv) > 3 else 4))

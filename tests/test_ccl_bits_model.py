@@ -15,3 +15,13 @@ def test_model_matches_brute_force(seed):
     import ccl_bits_model as m
     agg = m.run(seed, 120)
     assert agg["tiles"] > 100 and agg["check"] > 20 and agg["flood"] > 100      # both the shortcut and the flood were exercised
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 10])
+def test_model_other_window_sizes(n):
+    import ccl_bits_model as m
+    try:
+        agg = m.run(10 + n, 60, n)
+        assert agg["tiles"] > 50 and agg["flood"] > 20
+    finally:
+        m.configure(4)
