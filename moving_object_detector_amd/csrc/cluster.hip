@@ -618,16 +618,18 @@ template <int TH, int NMAX, int NW, bool EXACT>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_ccl_tile_list(DevCam c, ClArgs a, int tiles_x, int tiles_y) {
   __shared__ int s_next;
   const int count = a.counters[4];
-  for (;;) {
-    if (threadIdx.x == 0 && threadIdx.y == 0) s_next = atomicAdd(&a.counters[3], 1);
-    __syncthreads();
-    const int i = __builtin_amdgcn_readfirstlane(s_next);
-    if (i >= count) return;
+  // workgroup i starts with list entry i (a short list — the usual case — costs the other workgroups one scalar load), further
+  // entries are pulled with the cursor, which starts behind the statically assigned ones
+  int i = (int)blockIdx.x;
+  const int per_frame = tiles_x * tiles_y;
+  while (i < count) {
     const uint32_t t = a.tilelist[i];
-    const int per_frame = tiles_x * tiles_y;
     const int f = (int)(t / (uint32_t)per_frame), r = (int)(t - (uint32_t)f * (uint32_t)per_frame), ty = r / tiles_x, wi = r - ty * tiles_x;
     ccl_tile_body<TH, NMAX, NW, EXACT>(c, a, wi, ty, f, tiles_x, tiles_y);
     __syncthreads();                                 // the next tile re-uses the LDS arrays and s_next
+    if (threadIdx.x == 0 && threadIdx.y == 0) s_next = (int)gridDim.x + atomicAdd(&a.counters[3], 1);
+    __syncthreads();
+    i = __builtin_amdgcn_readfirstlane(s_next);
   }
 }
 
