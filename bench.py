@@ -320,9 +320,13 @@ def run():
     else:
         cam, host = synth.make_batch(W, H, G, seed=0, first_frame=rank * G, camera=args.camera)
     idx = [i % G for i in range(F)]
-    d_now = torch.from_numpy(np.ascontiguousarray(host["disparity_now"])).to(dev)[idx].contiguous()
-    d_prev = torch.from_numpy(np.ascontiguousarray(host["disparity_prev"])).to(dev)[idx].contiguous()
-    flow = torch.from_numpy(np.ascontiguousarray(host["flow"])).to(dev)[idx].contiguous()
+    # the three input planes come from one block with staggered bases, like the six output planes (pipeline.PLANE_STAGGER_BYTES)
+    from moving_object_detector_amd.pipeline import staggered
+    d_now, d_prev, flow = staggered([F * H * W, F * H * W, 2 * F * H * W], torch.float32, dev)
+    d_now, d_prev, flow = d_now.view(F, H, W), d_prev.view(F, H, W), flow.view(F, H, W, 2)
+    d_now.copy_(torch.from_numpy(np.ascontiguousarray(host["disparity_now"])).to(dev)[idx])
+    d_prev.copy_(torch.from_numpy(np.ascontiguousarray(host["disparity_prev"])).to(dev)[idx])
+    flow.copy_(torch.from_numpy(np.ascontiguousarray(host["flow"])).to(dev)[idx])
     ts, qs, dts = host["t"][idx], host["q"][idx], host["dt"][idx]
 
     ctx = Context(W, H, max_frames=F, device=local_rank)

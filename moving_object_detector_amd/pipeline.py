@@ -17,6 +17,24 @@ OBJECT_DTYPE = np.dtype([("id", "<i4"), ("n_points", "<i4"), ("center", "<f8", 3
 assert OBJECT_DTYPE.itemsize == capi.MOD_OBJECT_BYTES
 
 
+# Planes of one call are carved from ONE block with their bases 1 MiB further apart than their size: at 512 x 1280 x 720 a plane is a
+# multiple of 8 MiB, so back to back the nine streams of a scene-flow wave (3 in, 6 out) would carry the same low address bits — the
+# same DRAM bank group at the same moment.  Measured inside one process (tools/ab_skew.py): -1 ... -3 % on the scene-flow kernel for
+# 128 KiB ... 1 MiB of stagger (multiples of 2 MiB: nothing), depending on how (un)lucky the box's back-to-back placement is.
+PLANE_STAGGER_BYTES = 1 << 20
+
+
+def staggered(sizes, dtype, device, stagger_bytes: int = PLANE_STAGGER_BYTES):
+    """1-D tensors of `sizes` elements each, carved from one allocation, consecutive bases `stagger_bytes` apart beyond their sizes."""
+    skew = stagger_bytes // torch.empty((), dtype=dtype).element_size()
+    flat = torch.empty(sum(sizes) + skew * (len(sizes) - 1), dtype=dtype, device=device)
+    out, at = [], 0
+    for n in sizes:
+        out.append(flat[at:at + n])
+        at += n + skew
+    return out
+
+
 class Context:
     """One context per GPU / stream (single caller), like one SceneFlowConstructor + one ClustererNodelet."""
 
@@ -85,7 +103,9 @@ class Context:
             return self._ws
         H, W, dev = self.height, self.width, self.device
         ws = {"key": key}
-        ws["planes"] = torch.empty((6, frames, H, W), dtype=torch.float32, device=dev)
+        per = frames * H * W                             # six planes from one block, bases staggered (see PLANE_STAGGER_BYTES)
+        skew = PLANE_STAGGER_BYTES // 4
+        ws["planes"] = torch.empty(6 * per + 5 * skew, dtype=torch.float32, device=dev).as_strided((6, frames, H, W), (per + skew, H * W, W, 1))
         ws["mask"] = torch.empty((frames, H, self.mask_words), dtype=torch.int64, device=dev)
         ws["labels"] = torch.empty((frames, H, W), dtype=torch.int32, device=dev) if labels else None
         ws["objects"] = torch.zeros((frames, self.max_objects, capi.MOD_OBJECT_BYTES), dtype=torch.uint8, device=dev)
