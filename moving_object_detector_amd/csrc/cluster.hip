@@ -748,7 +748,9 @@ __device__ __forceinline__ uint64_t lane_bits(uint32_t lo, uint32_t hi, int l) {
 }
 
 // one tile (= one wave) per workgroup: 1 / 2 / 4 / 8 tiles per workgroup measured 0.451 / 0.455 / 0.521 / 0.642 ms per 512 pairs
-// (in-process A/B): a workgroup's slot and LDS stay occupied until its slowest wave is done, and three quarters of the tiles are empty
+// (in-process A/B): a workgroup's slot and LDS stay occupied until its slowest wave is done, and three quarters of the tiles are empty.
+// (One wave walking a STRIP of 2 / 4 / 5 / 10 tiles, to save the empty tiles' launches — 0.17 ms per 512 pairs when no pixel is
+// dynamic —: 0.495 / 0.495 / 0.510 / 0.515 against 0.435: active tiles sit next to each other and would queue behind one wave.)
 constexpr int kTilesPerBlock = 1, kMaxClasses = 4, kMaxComps = 32;
 
 // Global accesses of this kernel: ONE wave-uniform base per plane (frame's plane, in SGPRs) + a 32-bit byte offset per lane — the
@@ -1033,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_tile_flags(DevCam c, ClArgs a, int tile
 // hook), so what matters is how many are in flight, not which wave owns which tile.  A request is (halo pixel h, tile root r):
 // h's own tile has published parent[h] = its tile root by now, so the union is between two tile roots — all parent writes
 // here are atomicMin hooks on root entries.  Consecutive requests usually name the same pair; only the first lane of a run acts.
-constexpr int kLinkTiles = 8;
+constexpr int kLinkTiles = 32;   // 4 / 8 / 16 / 32 / 64 tiles per workgroup: 0.138 / 0.108 / 0.093 / 0.083 / 0.093 ms per 512 pairs (in-process A/B)
 
 __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_per_frame) {
   const int f = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -1941,8 +1943,10 @@ void launch_select(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *tm
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
 }
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  if (a.xy_from_z) hipLaunchKernelGGL((k_final<kTileH, kTileWaves, true>), tile_grid(c, frames), dim3(64, kTileWaves, 1), 0, s, c, a);
-  else hipLaunchKernelGGL((k_final<kTileH, kTileWaves, false>), tile_grid(c, frames), dim3(64, kTileWaves, 1), 0, s, c, a);
+  // two waves per tile (8 rows each): 2 / 4 / 8 waves measured 0.965 / 1.001 / 1.460 ms per 512 pairs (in-process A/B)
+  constexpr int kFinalWaves = 2;
+  if (a.xy_from_z) hipLaunchKernelGGL((k_final<kTileH, kFinalWaves, true>), tile_grid(c, frames), dim3(64, kFinalWaves, 1), 0, s, c, a);
+  else hipLaunchKernelGGL((k_final<kTileH, kFinalWaves, false>), tile_grid(c, frames), dim3(64, kFinalWaves, 1), 0, s, c, a);
 }
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // one 1024-thread workgroup fills a CU and costs ~80 ns of wave dispatch whether it finds work or not: launch at most one
