@@ -21,7 +21,7 @@ def _prm(csize=3, n=4):
     return synth.Params(cluster_size=csize, neighbor_distance=n, depth_diff=0.15, dynamic_speed=0.3)
 
 
-@pytest.mark.parametrize("shape", [(200, 150), (320, 16), (64, 200), (131, 77), (640, 480)])
+@pytest.mark.parametrize("shape", [(200, 150), (320, 16), (64, 200), (131, 77), (640, 480), (40, 30), (17, 20), (65, 17)])
 @pytest.mark.parametrize("density", [0.01, 0.08, 0.3, 0.97])
 def test_one_class_noise(oracle, shape, density):
     W, H = shape
