@@ -634,14 +634,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_ccl_bits — the tile stage on BIT PLANES, for the tiles whose depth gate cannot fire (neighbor_distance = 4, the reference's
-// default, Clusterer.cfg:11).
+// k_ccl_bits<n> — the tile stage on BIT PLANES, for the tiles whose depth gates are decided by a few DEPTH CLASSES; one instance per
+// neighbor_distance n = 1 .. 10 (Clusterer.cfg:11; the description uses the default n = 4).
 //
 // comparePoints links two dynamic pixels unless |z_p - z_q| > depth_diff (clusterer_nodelet.cpp:186-219).  When the dynamic cells
-// of a tile and its halo span no more than depth_diff in depth — a tile inside or at the rim of one object: four fifths of the
-// active tiles of the synthetic street scene — no gate of the tile can fire, and its components are those of the MASK under the
-// up-left 5 x 5 window.  They are found without touching a pixel: ONE wave per tile, lane = grid row (4 halo rows above + 16 tile
-// rows), a row = 68 bits (4 halo columns + 64) in three registers, so that
+// of a tile and its halo, sorted by depth, fall into stretches that are each no wider than depth_diff and clear of each other by
+// more than it (a tile inside one object: one stretch; at an object's rim: two — 99 % of the active tiles of the synthetic street
+// scene need at most four), every gate inside a stretch passes and every gate between two fires: the tile's components are those of
+// each stretch's MASK under the up-left 5 x 5 window.  They are found without touching a pixel: ONE wave per tile, lane = grid row
+// (4 halo rows above + 16 tile rows), a row = 68 bits (4 halo columns + 64) in three registers, so that
 //   * "has an up-left edge" (first_edge_key), "is somebody's up-left neighbour" and the closing of <= 3-cell gaps are a few
 //     shifts / ORs per row, the rows above / below arrive by DPP wave shifts;
 //   * the usual tile (every row one closed run, every row linked to a row above) is ONE component by inspection;
