@@ -262,6 +262,11 @@ def run():
             raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
         if args.share_device:
             local_rank = 0
+        # a launcher may hand every rank ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank): the device index
+        # is then 0 whatever LOCAL_RANK says; with all devices visible it is LOCAL_RANK
+        ndev = torch.cuda.device_count()
+        if ndev and local_rank >= ndev:
+            local_rank = local_rank % ndev
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if not args.launch_check else torch.device("cpu")
     on_dev = args.backend == "nccl" and not args.launch_check
