@@ -229,18 +229,25 @@ static_assert(kSfArgsAt == offsetof(SfKernargLayout, a), "SfArgs does not sit wh
 // Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
 __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const int lane = threadIdx.x;                      // 0..63
-  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), and each XCD has
-  // its own L2.  Remapping the linear id so that XCD k walks the k-th contiguous eighth of the batch keeps the rows a
-  // block's flow-warp gathers touch in the L2 that fetched them for the neighbouring blocks.
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), and each XCD has its
+  // own L2.  Here XCD k takes every 8th ROW of blocks (4 image rows, all of their x blocks): the blocks in flight still cover ONE
+  // contiguous window of each plane (about 1.4 frames), as in plain dispatch order, and the rows a block's flow-warp gathers touch
+  // are in the L2 that fetched them for its x neighbours.  In-process A/B (tools/ab_inproc.py, 512 pairs, boxes A / B / C): XCD k on
+  // the k-th contiguous EIGHTH of the batch (rounds 1-3: eight windows per plane) 3.387 / 3.611 / 3.561 ms; this order 3.331 /
+  // 3.507 / 3.475 (-1.7 ... -2.9 %); plain dispatch order 3.346 (A), 3.471 (C); runs of 2 / 4 / 9 / 45 block rows per XCD
+  // 3.523 / 3.521 / 3.564 / 3.708 (B); XCD k on frames = k (mod 8) 3.408 (A); all XCDs inside one pair of frames, an eighth each,
+  // 3.552 (A); frame-linear blocks (4 consecutive 256-px segments) 3.631 (C).  The coarser the interleave, the slower.  It also
+  // makes the kernel insensitive to where the planes sit (tools/ab_skew.py: 3.37-3.38 ms for every stagger from 4 KiB to 2 MiB,
+  // 3.40 back to back).
   uint32_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   {
-    const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
-    if ((total & 7u) == 0u && !MOD_ABLATE(c, 64)) {
+    const uint32_t rows = gridDim.y * gridDim.z;             // block rows of the batch
+    if ((rows & 7u) == 0u && !MOD_ABLATE(c, 64)) {
       const uint32_t lin = bx + gridDim.x * (by + gridDim.y * bz);
-      const uint32_t m = (lin & 7u) * (total >> 3) + (lin >> 3);
-      bx = m % gridDim.x;
-      const uint32_t t = m / gridDim.x;
-      by = t % gridDim.y; bz = t / gridDim.y;
+      const uint32_t j = lin >> 3, k = lin & 7u;             // k: the XCD this block was dealt to, j: its turn there
+      const uint32_t r = j / gridDim.x * 8u + k;             // block row
+      bx = j % gridDim.x;
+      by = r % gridDim.y; bz = r / gridDim.y;
     }
   }
   const int x0 = (bx * 64 + lane) * 4;

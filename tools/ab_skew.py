@@ -12,6 +12,8 @@ N = W * H
 cam, sq = synth.make_sequence(W, H, G, seed=4)
 idx = [i % G for i in range(F)]
 dev = torch.device("cuda:0")
+if os.environ.get("LIB"):                              # another build of the library (name under moving_object_detector_amd/)
+    capi.LIB_PATH = os.path.join(ROOT, "moving_object_detector_amd", os.environ["LIB"])
 d = torch.from_numpy(sq["disparity"]).to(dev)
 d_now0, d_prev0 = d[1:][idx].contiguous(), d[:-1][idx].contiguous()
 flow0 = torch.from_numpy(sq["flow"]).to(dev)[idx].contiguous()
