@@ -15,6 +15,11 @@ dev = torch.device("cuda:0")
 d = torch.from_numpy(sq["disparity"]).to(dev)
 d_now, d_prev = d[1:][idx].contiguous(), d[:-1][idx].contiguous()
 flow = torch.from_numpy(sq["flow"]).to(dev)[idx].contiguous()
+if int(os.environ.get("STAGGER_IN", "0")):             # the three input planes laid out as bench.py lays them out
+    a, b, c = pipeline.staggered([F * H * W, F * H * W, 2 * F * H * W], torch.float32, dev)
+    a, b, c = a.view(F, H, W), b.view(F, H, W), c.view(F, H, W, 2)
+    a.copy_(d_now); b.copy_(d_prev); c.copy_(flow)
+    d_now, d_prev, flow = a, b, c
 ts, qs, dts = sq["t"][idx], sq["q"][idx], sq["dt"][idx]
 ctxs = []
 ws = None

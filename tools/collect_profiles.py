@@ -8,6 +8,20 @@ os.makedirs("profiles", exist_ok=True)
 bench = json.load(open(f"{src}/bench_default.json"))
 json.dump(bench, open(f"profiles/{tag}_bench.json", "w"), indent=1)
 stats = max(glob.glob(f"{src}/stats/*/*_kernel_stats.csv"), key=os.path.getmtime)   # newest run only
+# tools/stats3.sh ran on the same box: the committed summary is the MEDIAN of its three traced runs (by the scene-flow kernel's
+# average), together with the line that very process printed
+three = []
+for d in sorted(glob.glob("gpurun_out/final_stats[0-9]")):
+    fs = glob.glob(f"{d}/*/*_kernel_stats.csv")
+    if not fs or not os.path.getsize(f"{d}/bench.json"): continue
+    avg = [float(r["AverageNs"]) for r in csv.DictReader(open(fs[0])) if "k_scene_flow" in r["Name"]]
+    if avg: three.append((avg[0], fs[0], f"{d}/bench.json"))
+stats_line = f"{src}/stats_bench.json"
+if len(three) == 3:
+    three.sort()
+    print("traced runs, scene-flow kernel avg us:", [round(t[0] / 1e3, 1) for t in three], "-> committing the median")
+    stats, stats_line = three[1][1], three[1][2]
+json.dump(json.load(open(stats_line)), open(f"profiles/{tag}_stats_bench.json", "w"), indent=1)
 rows = list(csv.DictReader(open(stats)))
 with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
