@@ -7,12 +7,16 @@ import numpy as np
 import torch
 from moving_object_detector_amd import synth
 from moving_object_detector_amd.pipeline import Context
+from moving_object_detector_amd import capi
 from oracle import pyoracle
 from util import PLANES, bits_equal, compare_objects, first_mismatch
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 pyoracle.lib()
+# MOD_SF_LIB=.../libmod_sf_checked.so: the CHECKED build (csrc/mod_device.h MOD_CHECK) counts every data-derived index that fails its
+# test instead of using it; the soak then also requires all those counters to stay 0
+CHECKED = "checked" in os.path.basename(capi.LIB_PATH)
 t_end = time.time() + budget
 it = 0
 while time.time() < t_end:
@@ -46,6 +50,14 @@ while time.time() < t_end:
     ctx.synchronize()
     planes = ws["planes"].cpu().numpy(); labels = ws["labels"].cpu().numpy(); objs = ctx.objects_to_host(ws)
     sflow = ws["static_flow"].cpu().numpy(); nclu = ws["n_clusters"].cpu().numpy()
+    if CHECKED:
+        import ctypes as C
+        cnt = (C.c_uint64 * 96)()
+        ctx.lib.mod_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        assert ctx.lib.mod_debug_counters(ctx.h, cnt) == 0
+        bad = {i - 64: int(cnt[i]) for i in range(64, 96) if cnt[i]}
+        if bad:
+            print("MISMATCH index check (code: count)", bad, dict(W=W, H=H, F=F, seed=seed, prm=prm)); sys.exit(1)
     ctx.close()
     nobj = namb = 0
     for f in range(F):
@@ -65,4 +77,4 @@ while time.time() < t_end:
             print("MISMATCH objects", dict(W=W, H=H, F=F, seed=seed, f=f, prm=prm), e); sys.exit(1)
         nobj += len(ro)
     print(f"ok #{it}: {W}x{H}x{F} seed {seed} mode {mode} n={prm.neighbor_distance} cs={prm.cluster_size} dd={prm.depth_diff} ds={prm.dynamic_speed} fd={prm.dynamic_flow_diff}: {nobj} objects", flush=True)
-print("soak passed:", it, "configurations")
+print("soak passed:", it, "configurations" + (" (checked build, no index violation)" if CHECKED else ""))
