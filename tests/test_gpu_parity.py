@@ -178,3 +178,14 @@ def test_nominal_workload_1280x720_sequence(oracle):
     out = _run_gpu(cam, prm, batch)
     _check_against_oracle(oracle, cam, prm, batch, out)
     assert sum(len(o) for o in out["objects"]) >= 6
+
+
+def test_4k_frame(oracle):
+    """Largest shape exercised: one 3840x2160 pair (8.3 M px, 9x the 720p frame: 32-bit in-frame byte offsets, 60 x 135 tiles,
+    clusters of several hundred thousand pixels), reference default parameters."""
+    from moving_object_detector_amd import synth
+    cam, batch = synth.make_batch(3840, 2160, 1, seed=23)
+    prm = synth.Params()
+    out = _run_gpu(cam, prm, batch, aos=True)
+    _check_against_oracle(oracle, cam, prm, batch, out)
+    assert len(out["objects"][0]) >= 1
