@@ -1944,7 +1944,8 @@ void launch_select(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *tm
   hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
 }
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
-  // two waves per tile (8 rows each): 2 / 4 / 8 waves measured 0.965 / 1.001 / 1.460 ms per 512 pairs (in-process A/B)
+  // two waves per tile (8 rows each): 1 / 2 / 4 / 8 waves measured 1.419 (176 VGPRs: 2 waves per SIMD) / 0.965 / 1.001 / 1.460 ms per 512
+  // pairs (in-process A/B)
   constexpr int kFinalWaves = 2;
   if (a.xy_from_z) hipLaunchKernelGGL((k_final<kTileH, kFinalWaves, true>), tile_grid(c, frames), dim3(64, kFinalWaves, 1), 0, s, c, a);
   else hipLaunchKernelGGL((k_final<kTileH, kFinalWaves, false>), tile_grid(c, frames), dim3(64, kFinalWaves, 1), 0, s, c, a);
