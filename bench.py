@@ -32,6 +32,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0
+# measured on this pool in round 4 with timing-only builds of the scene-flow kernel (profiles/README.md): its plane stores alone run at
+# 5.65 TB/s whether one plane or six are written and whatever the cache policy, its loads alone at 6.4 TB/s, and both together take
+# the SUM of the two — so 24 B written + 16 B read per pixel cannot move faster than 40 / (24 / 5650 + 16 / 6400) = 5.93 TB/s
+HBM_WRITE_GBS, HBM_READ_GBS = 5650.0, 6400.0
+SF_RW_BOUND_GBS = 40.0 / (24.0 / HBM_WRITE_GBS + 16.0 / HBM_READ_GBS)
 B_SCENE_FLOW = 40              # bytes/px: read disp_now 4 + disp_prev 4 + flow 8, write x,y,z,vx,vy,vz 24
 B_CLUSTER = 20                 # bytes/px: read z,vx,vy,vz 16, write label 4
 B_FUSED = 44                   # bytes/px: 16 in + 24 out + 4 label (mask never round-trips as a plane)
@@ -409,6 +414,7 @@ def run():
             "frames_per_launch": F, "avg_launch_ms": ms[dom],
             "measured_in": "timed region" if dom == capi.MOD_STAGE_SCENE_FLOW else "breakdown pass (all stage timers on)",
             "scene_flow_ms_in_breakdown_pass": breakdown_sf_ms, "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
+            "frac_of_measured_read_write_bound": (ach / SF_RW_BOUND_GBS) if dom == capi.MOD_STAGE_SCENE_FLOW else None,
             "traffic_from_committed_profile": traffic is not None,       # a separate rocprofv3 --pmc run of this command, not this run
             "traffic_source": (f"profiles/{os.path.basename(tpath)} at commit {tj.get('head', '?')} (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 + "
                                f"WRITE_SIZE in separate passes of this same command; counters cannot be read inside the run)"
