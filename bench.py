@@ -270,8 +270,13 @@ def run():
         # a launcher may hand every rank ONE visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank): the device index
         # is then 0 whatever LOCAL_RANK says; with all devices visible it is LOCAL_RANK
         ndev = torch.cuda.device_count()
-        if ndev and local_rank >= ndev:
-            local_rank = local_rank % ndev
+        if ndev == 1:
+            local_rank = 0
+        elif local_rank >= ndev:
+            # fewer visible devices than ranks per node (and more than one): folding ranks onto the same GPU would report
+            # throughput from oversubscribed devices — refuse (--share-device is the deliberate one-GPU rehearsal)
+            raise RuntimeError(f"LOCAL_RANK {local_rank} but only {ndev} visible devices: launch one rank per visible GPU "
+                               f"(or expose exactly one device per rank)")
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if not args.launch_check else torch.device("cpu")
     on_dev = args.backend == "nccl" and not args.launch_check
@@ -440,7 +445,7 @@ def run():
             except Exception as e:                            # noqa: BLE001  (the leg is outside `value`; its failure must not cost the line)
                 c5 = {"error": f"{type(e).__name__}: {e}"[:300]}
         cpu = None
-        if not args.no_cpu_baseline:                     # rank 0 only, also when N > 1 (the other ranks wait at the last barrier)
+        if not args.no_cpu_baseline:                     # rank 0 only, also when N > 1 (the group is down by now: the other ranks have left)
             prm = synth.Params()
             cpu, refs = cpu_baseline(cam, prm, host, args.cpu_sample, sgm=c5_check)
             ok = True

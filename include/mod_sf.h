@@ -26,6 +26,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libmod_sf.so is built with -fvisibility=hidden: the declarations of this header are its whole dynamic symbol table
+ * (tests/test_abi.py checks `nm -D --defined-only`). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define MOD_ABI_VERSION 1
 
@@ -249,7 +254,11 @@ int  mod_cluster_cloud_host(ModContext *ctx, const void *cloud, int32_t width, i
  *       to or from pageable memory makes the call wait for that copy; `objects` may be ordinary memory (filled at collect time).
  *   mod_collect_frame_host waits for a ticket (tickets complete in submission order; the oldest one must be collected
  *       first) and reports its object count.
- * Camera / parameters must not be changed while frames are in flight. */
+ * Reconfiguration while frames are in flight: the PARAMETERS may change between two submits (mod_set_params; the reference's
+ * reconfigureCB runs between two stereoCallbacks, scene_flow_constructor.cpp:401-407) — every kernel takes them by value at
+ * submit time, so a frame in flight completes with the parameters of ITS submit and the next submit uses the new ones
+ * (tests/test_gpu_host_stream.py).  The CAMERA must not change while frames are in flight (its ray tables live in HBM and are
+ * read by the kernels of the frames in flight): collect every ticket first. */
 #define MOD_PIPELINE_DEPTH 3
 int  mod_submit_frame_host(ModContext *ctx,
                            const float *disparity_now, const float *disparity_prev, const float *flow,
@@ -293,12 +302,13 @@ int  mod_memcpy_d2h(ModContext *ctx, void *host_dst, const void *dev_src, uint64
  * bracketed by HIP events on the context's stream in the calls that follow.  Every event pair costs a few microseconds of
  * stream time, so a throughput measurement should select only the stage it prices. */
 #define MOD_STAGE_SCENE_FLOW  0   /* k_scene_flow_v4 / _v1: fused scene-flow kernel (+ dynamic mask)            */
-#define MOD_STAGE_CCL_TILE    1   /* k_ccl_tile: tile-local connected components (+ k_dynamic_mask if needed)   */
+#define MOD_STAGE_CCL_TILE    1   /* tile stage: k_ccl_bits<n> + k_ccl_tile_list (k_ccl_tile for n > 10): tile-local
+                                     connected components (+ k_dynamic_mask / k_tile_flags for a caller's cloud)  */
 #define MOD_STAGE_CCL_LINK    2   /* k_ccl_link: cross-tile unions                                              */
 #define MOD_STAGE_CCL_MERGE   3   /* k_ccl_merge: root-level flatten + record folding                           */
 #define MOD_STAGE_SELECT      4   /* k_select: size filter, reference numbering, bbox/centre                    */
 #define MOD_STAGE_FINAL       5   /* k_final: labels plane + member compaction                                  */
-#define MOD_STAGE_MEDIAN      6   /* k_median + k_finalize: median-velocity member, object ids                  */
+#define MOD_STAGE_MEDIAN      6   /* k_median + k_median_ties + k_finalize: median-velocity member, object ids  */
 #define MOD_STAGE_COUNT       7
 #define MOD_PROFILE_ALL        0x7f
 int  mod_set_profiling(ModContext *ctx, int32_t stage_mask);
@@ -306,6 +316,9 @@ int  mod_set_profiling(ModContext *ctx, int32_t stage_mask);
 int  mod_get_stage_time(ModContext *ctx, int32_t stage, double *total_ms, int64_t *calls);
 int  mod_reset_stage_times(ModContext *ctx);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

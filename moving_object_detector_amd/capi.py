@@ -29,7 +29,7 @@ MOD_STAGE_SCENE_FLOW, MOD_STAGE_CCL_TILE, MOD_STAGE_CCL_LINK, MOD_STAGE_CCL_MERG
 MOD_STAGE_SELECT, MOD_STAGE_FINAL, MOD_STAGE_MEDIAN, MOD_STAGE_COUNT = 4, 5, 6, 7
 MOD_PROFILE_ALL = 0x7F
 MOD_PIPELINE_DEPTH = 3
-STAGE_NAMES = ("k_scene_flow", "k_ccl_tile", "k_ccl_link", "k_ccl_merge", "k_select", "k_final", "k_median+k_finalize")
+STAGE_NAMES = ("k_scene_flow", "k_ccl_bits+k_ccl_tile_list", "k_ccl_link", "k_ccl_merge", "k_select", "k_final", "k_median+k_median_ties+k_finalize")
 
 # every symbol include/mod_sf.h declares (tests check that the library exports all of them)
 EXPORTS = [

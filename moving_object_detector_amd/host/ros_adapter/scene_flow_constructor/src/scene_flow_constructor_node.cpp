@@ -15,8 +15,9 @@
 //                    planes that are still in HBM — one clustering per frame, no 29.5 MB PointCloud2 hand-off between two processes
 //                    (detect_moving_object.launch:19-33 wires constructor -> topic -> clusterer; INTEGRATION.md section 3 has the two
 //                    launch-file lines that drop the separate clusterer).  The clusterer's four parameters are read from
-//                    `~clusterer/{cluster_size, depth_diff, dynamic_speed, neighbor_distance}` (Clusterer.cfg defaults) and served by a
-//                    second dynamic_reconfigure server in that namespace.  With the parameter false the node is the reference's
+//                    `~clusterer/{cluster_size, depth_diff, dynamic_speed, neighbor_distance}` (Clusterer.cfg's names, defaults and ranges) and served by a
+//                    second dynamic_reconfigure server in that namespace from this package's own cfg/CollapsedClusterer.cfg — the
+//                    reference's clusterer package build-depends on this one, so its generated header cannot be used here.  With the parameter false the node is the reference's
 //                    constructor alone: no clustering runs here.
 //   ~scene_flow      the 32-byte cloud is packed and copied to the host only while somebody subscribes (:141-142 gates exactly so)
 // Not buildable in the image this was written in (no ROS): tests/test_ros_adapter_syntax.py compiles it against declaration-only
@@ -29,7 +30,7 @@
 #include <message_filters/time_synchronizer.h>
 #include <moving_object_msgs/MovingObjectArray.h>
 #include <ros/ros.h>
-#include <scene_flow_clusterer/ClustererConfig.h>
+#include <scene_flow_constructor/CollapsedClustererConfig.h>   // this package's own cfg/CollapsedClusterer.cfg (no dependency on scene_flow_clusterer)
 #include <scene_flow_constructor/SceneFlowConstructorConfig.h>
 #include <sensor_msgs/CameraInfo.h>
 #include <sensor_msgs/Image.h>
@@ -79,8 +80,8 @@ class SceneFlowConstructorNode {
     publish_moving_objects_ = private_node_handle_.param("publish_moving_objects", true);
     if (publish_moving_objects_) {
       clusterer_node_handle_ = ros::NodeHandle(private_node_handle_, "clusterer");
-      clusterer_reconfigure_server_.reset(new dynamic_reconfigure::Server<scene_flow_clusterer::ClustererConfig>(clusterer_node_handle_));
-      clusterer_reconfigure_server_->setCallback([this](scene_flow_clusterer::ClustererConfig &config, uint32_t) {
+      clusterer_reconfigure_server_.reset(new dynamic_reconfigure::Server<CollapsedClustererConfig>(clusterer_node_handle_));
+      clusterer_reconfigure_server_->setCallback([this](CollapsedClustererConfig &config, uint32_t) {
         impl_->reconfigureClusterer(config.cluster_size, config.depth_diff, config.dynamic_speed, config.neighbor_distance);
       });
       moving_objects_pub_ = private_node_handle_.advertise<moving_object_msgs::MovingObjectArray>("moving_objects", 1);
@@ -241,7 +242,7 @@ class SceneFlowConstructorNode {
   ros::Publisher depth_pub_, optflow_pub_, pc_with_velocity_pub_, static_flow_pub_, moving_objects_pub_;
   bool publish_moving_objects_ = true;
   ros::NodeHandle clusterer_node_handle_;
-  std::unique_ptr<dynamic_reconfigure::Server<scene_flow_clusterer::ClustererConfig>> clusterer_reconfigure_server_;
+  std::unique_ptr<dynamic_reconfigure::Server<CollapsedClustererConfig>> clusterer_reconfigure_server_;
   std::unique_ptr<mod_host::MovingObjectArray> pending_objects_;
   bool camera_set_ = false;
   float max_disparity_ = 127.0f;

@@ -31,6 +31,21 @@ def test_library_exports_every_declared_symbol():
     assert not hasattr(lib, "mod_debug_read") and not hasattr(lib, "mod_debug_counters")
 
 
+def test_library_exports_the_c_abi_and_nothing_else():
+    """A drop-in C library exports its C ABI only: `nm -D --defined-only` lists the declarations of include/mod_sf.h — no C++ launcher,
+    no template instantiation, no compiler-emitted global (csrc/Makefile: -fvisibility=hidden + csrc/exports.map)."""
+    import subprocess
+    from moving_object_detector_amd import capi
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert names == sorted(declared_functions()), set(names) ^ set(declared_functions())
+    checked = os.path.join(os.path.dirname(capi.LIB_PATH), "libmod_sf_checked.so")
+    if os.path.exists(checked):                      # the diagnostic twin adds csrc/mod_sf_debug.h's two entry points
+        out = subprocess.run(["nm", "-D", "--defined-only", checked], capture_output=True, text=True, check=True).stdout
+        extra = sorted(set(line.split()[-1] for line in out.splitlines() if line.strip()) - set(names))
+        assert extra == ["mod_debug_counters", "mod_debug_read"], extra
+
+
 def test_struct_layouts():
     from moving_object_detector_amd import capi
     assert C.sizeof(capi.ModObject) == 112

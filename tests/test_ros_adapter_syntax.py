@@ -61,11 +61,60 @@ def test_packaging():
             assert "moving_object_msgs" in deps
         if "nodelet/" in src:
             assert "nodelet" in deps and "pluginlib" in deps
-        if "scene_flow_clusterer/ClustererConfig.h" in src and pkg != "scene_flow_clusterer":
-            assert "scene_flow_clusterer" in deps
+        for other in ("scene_flow_clusterer", "scene_flow_constructor"):      # a generated header of the other package needs the dependency
+            if other != pkg and f"#include <{other}/" in src:
+                assert other in deps, (pkg, other)
         if "image_transport/" in src:
             assert "image_transport" in deps and "message_filters" in deps
     xml.dom.minidom.parse(os.path.join(ADAPTER, "scene_flow_clusterer", "nodelet_plugins.xml"))
+
+
+def test_no_dependency_cycle_with_the_reference_packages():
+    """The adapter packages REPLACE CMakeLists.txt / package.xml / src of two reference packages inside the reference's workspace.  The
+    reference's scene_flow_clusterer build-depends on scene_flow_constructor (scene_flow_clusterer/package.xml:18, CMakeLists.txt
+    find_package: pcl_point_xyz_velocity.h), and the adapter's clusterer keeps that edge out; the constructor must not depend on the
+    clusterer in return, in either manifest, or catkin cannot order the two."""
+    import re
+    import xml.dom.minidom
+
+    def deps_of(path):
+        doc = xml.dom.minidom.parse(path)
+        tags = ("depend", "build_depend", "build_export_depend", "exec_depend", "run_depend", "buildtool_depend")
+        return {d.firstChild.data.strip() for t in tags for d in doc.getElementsByTagName(t)}
+
+    edges = {pkg: deps_of(os.path.join(ADAPTER, pkg, "package.xml")) for pkg in ("scene_flow_constructor", "scene_flow_clusterer")}
+    ref = "/root/reference"
+    if os.path.isdir(ref):                               # the workspace the adapter is dropped into: every reference manifest
+        for name in os.listdir(ref):
+            px = os.path.join(ref, name, "package.xml")
+            if os.path.exists(px):
+                edges.setdefault(name, set())
+                if name not in ("scene_flow_constructor", "scene_flow_clusterer"):
+                    edges[name] |= deps_of(px)
+        assert "scene_flow_constructor" in deps_of(os.path.join(ref, "scene_flow_clusterer", "package.xml"))   # the fact the rule rests on
+    # either way of replacing: both adapter packages, or only one of them next to the reference's other one
+    for variant in ({}, {"scene_flow_clusterer": {"scene_flow_constructor"}}):
+        g = {k: set(v) for k, v in edges.items()}
+        for k, extra in variant.items():
+            g[k] |= extra
+        state = {}
+
+        def visit(n, path):
+            if state.get(n) == 1:
+                raise AssertionError("dependency cycle: " + " -> ".join(path + [n]))
+            if state.get(n) == 2 or n not in g:
+                return
+            state[n] = 1
+            for m in sorted(g[n]):
+                visit(m, path + [n])
+            state[n] = 2
+
+        for n in sorted(g):
+            visit(n, [])
+    cm = open(os.path.join(ADAPTER, "scene_flow_constructor", "CMakeLists.txt")).read()
+    comps = re.search(r"find_package\(catkin REQUIRED COMPONENTS(.*?)\)", cm, flags=re.S).group(1).split()
+    assert "scene_flow_clusterer" not in comps and "scene_flow_clusterer" not in edges["scene_flow_constructor"]
+    assert "cfg/CollapsedClusterer.cfg" in cm and os.path.exists(os.path.join(ADAPTER, "scene_flow_constructor", "cfg", "CollapsedClusterer.cfg"))
 
 
 def test_plugin_identity():
