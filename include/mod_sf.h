@@ -122,7 +122,10 @@ typedef struct ModFrameBatch {
 
 /* ~scene_flow as SoA planes (+ optional reference-layout outputs). All device pointers, [frames][H][W]. */
 typedef struct ModSceneFlowPlanes {
-  float    *x, *y, *z, *vx, *vy, *vz;  /* required */
+  float    *x, *y, *z, *vx, *vy, *vz;  /* required — except x and y in mod_process_dev (both or neither): the reference builds and ships
+                                          the cloud only for subscribers (scene_flow_constructor.cpp:141-142); a caller that serves the
+                                          moving objects alone passes x = y = NULL, the scene-flow kernel then writes 16 instead of 24
+                                          bytes per pixel and the cluster stage recomputes its members' x, y from z (bit-identical) */
   uint64_t *dynamic_mask;  /* optional [frames][H][mod_mask_words(W)]: bit b of word k of a row = pixel 64k+b is dynamic
                               (calculateDynamicMap, clusterer_nodelet.cpp:40-54) */
   void     *cloud_aos;     /* optional [frames][H][W] 32-byte pcl::PointXYZVelocity records
@@ -182,7 +185,8 @@ int  mod_dynamic_mask_dev(ModContext *ctx, int32_t frames, const float *vx, cons
  * planes->dynamic_mask may be NULL (computed internally). */
 int  mod_cluster_dev(ModContext *ctx, int32_t frames, const ModSceneFlowPlanes *planes, const ModClusterOut *out);
 
-/* Both stages back to back without the PointCloud2 round trip (the mask is produced by the scene-flow kernel). */
+/* Both stages back to back without the PointCloud2 round trip (the mask is produced by the scene-flow kernel).
+ * planes->x and planes->y may both be NULL (objects-only: see ModSceneFlowPlanes). */
 int  mod_process_dev(ModContext *ctx, const ModFrameBatch *in, const ModSceneFlowPlanes *planes, const ModClusterOut *out);
 
 /* pcl::toROSMsg / pcl::fromROSMsg payload conversion (scene_flow_constructor.cpp:358-361, clusterer_nodelet.cpp:226). */
@@ -224,9 +228,11 @@ int  mod_sgm_path_dev(ModContext *ctx, int32_t frames, const uint32_t *census_le
 /* ---- host-pointer convenience (what a ROS node with host-side messages calls) ----------------------------- */
 /* One frame, host buffers in/out; any output pointer may be NULL.  Returns a skip code exactly where construct()
  * would publish nothing.  cloud_aos: W*H*32 bytes; labels: W*H int32; objects: capacity `max_objects`.
- * With labels == NULL and objects == NULL the clustering stage does not run at all (the reference's constructor node does not
- * cluster; its clusterer runs whenever a cloud arrives, clusterer_nodelet.cpp:231): a node that serves ~scene_flow alone pays for
- * the scene-flow stage only.  The same holds for mod_submit_frame_host and mod_submit_stereo_host. */
+ * With labels == NULL, objects == NULL AND n_objects == NULL the clustering stage does not run at all (the reference's constructor
+ * node does not cluster; its clusterer runs whenever a cloud arrives, clusterer_nodelet.cpp:231): a node that serves ~scene_flow
+ * alone pays for the scene-flow stage only.  A caller that passes n_objects alone still gets the real count.  mod_submit_frame_host
+ * and mod_submit_stereo_host have no count pointer at submit time: there labels == NULL and objects == NULL select the scene-flow
+ * stage alone, and mod_collect_frame_host reports 0 objects for such a ticket. */
 int  mod_process_frame_host(ModContext *ctx,
                             const float *disparity_now, const float *disparity_prev, const float *flow,
                             const ModTransform *transform, double dt,

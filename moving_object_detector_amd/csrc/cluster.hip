@@ -806,14 +806,33 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
   __shared__ float zlds[kTilesPerBlock][PH][64];
   float(*zl)[64] = zlds[wv];
   float zh[HL];
-  {
-    const int gy = min(max(y0 - HL + lane, 0), H - 1);                 // (lanes >= PH read the clamped last row: never used)
-    const uint32_t ho = 4u * (uint32_t)(gy * W + max(x0 - HL, 0));     // wi == 0 has no halo columns (Mrem.h == 0)
-#pragma unroll
-    for (int j = 0; j < HL; j++) zh[j] = ldo<float>(zplane, ho + 4u * j);
-  }
   float lo = qnan, hi = qnan;
-  {
+  // Round 5: the fused scene-flow kernel leaves, next to every non-zero mask word, the smallest and largest depth of the word's
+  // dynamic pixels (ClArgs.zrange).  The union of the ranges of this tile's words (word wi of the grid rows; word wi - 1 of the rows
+  // whose halo columns hold a dynamic cell — that word spans 64 columns, the halo HL of them, so the union can only be WIDER than the
+  // grid's own range) no wider than depth_diff means ONE class (F32 subtraction is monotone: hi - lo of a subset cannot round
+  // above that of its superset) and NO depth row is loaded at all; otherwise, and for a caller's cloud (zrange == null), the
+  // depths are read as before.  A sufficient test only: the result is the same either way.
+  bool need_z = true;
+  if (a.zrange) {                                                      // wave-uniform
+    const int gy = y0 - HL + lane;
+    const bool inrow = lane < PH && gy >= 0 && gy < H;
+    const float2 *zr = a.zrange + ((size_t)f * H + (inrow ? gy : 0)) * MW;
+    const float2 r0 = zr[wi], rL = zr[max(wi - 1, 0)];                 // unconditional loads, clamped addresses (beside the mask words')
+    const bool u0 = (Mrem.a | Mrem.b) != 0u, uL = Mrem.h != 0u;        // Mrem is zero outside the grid's rows
+    lo = zmin(u0 ? r0.x : qnan, uL ? rL.x : qnan); hi = zmax(u0 ? r0.y : qnan, uL ? rL.y : qnan);
+    lo = wave_fmin(lo); hi = wave_fmax(hi);
+    need_z = hi - lo > th;                                             // (a NaN — impossible here — would take the row path's answer below)
+  }
+  if (need_z) {
+    lo = qnan; hi = qnan;
+    {
+      const int gy = min(max(y0 - HL + lane, 0), H - 1);               // (lanes >= PH read the clamped last row: never used)
+      // wi == 0 has no halo columns (Mrem.h == 0); an image narrower than HL still reads inside its rows (values unused)
+      const int hx = max(x0 - HL, 0);
+#pragma unroll
+      for (int j = 0; j < HL; j++) zh[j] = ldo<float>(zplane, 4u * (uint32_t)(gy * W + min(hx + j, W - 1)));
+    }
     uint64_t nanb = 0ull;
     constexpr int HB = (PH + 1) / 2;                                   // two batches of rows (10 + 10 at HL = 4)
 #pragma unroll
@@ -847,6 +866,9 @@ __global__ __launch_bounds__(64 * kTilesPerBlock) void k_ccl_bits(DevCam c, ClAr
       if (lane == 0) a.tilelist[atomicAdd(&a.counters[4], 1)] = (uint32_t)tix;
       return;
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < HL; j++) zh[j] = qnan;                         // never read: one class ends the loop below after its first pass
   }
   for (int pass = 0;; pass++) {                                        // wave-uniform
     if (pass == kMaxClasses) { bail = true; break; }
@@ -1098,7 +1120,10 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
     } else {
       parent[p] = r;   // r is final: no union runs after k_ccl_link
       const int sz = rsize[p], ky = rkey[p];
-      atomicAdd(&rsize[r], sz);
+      // the running sum the add returns is this tile root's place among the component's members: [old, old + sz) of the component's
+      // member segment (the final root's own tile pixels hold [0, its count): rsize[r] starts there).  Parked in the tile root's key
+      // entry, which nobody reads again as a key — k_final takes it from there instead of reserving slots with an atomic of its own.
+      rkey[p] = atomicAdd(&rsize[r], sz);
       if (ky != kKeyNone) atomicMin(&rkey[r], ky);
     }
   }
@@ -1145,7 +1170,6 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
     ci.pad[0] = ci.pad[1] = 0;
     C[rank] = ci;
     rkey[ci.comp] = rank;                               // k_final looks the new label up here
-    a.cursors[(size_t)f * a.max_objects + rank] = 0;
     ClusterBox bx;
     for (int d = 0; d < 8; d++) bx.w[d] = 0xffffffffu;
     a.cbox[(size_t)f * a.max_objects + rank] = bx;      // k_final folds the members' x, y, z into it
@@ -1153,7 +1177,9 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
   __syncthreads();
   if (tid == 0) {
     int off = 0;
-    for (int k = 0; k < K; k++) { C[k].offset = off; off += C[k].size; }
+    // the segment's start also goes to the final root's size entry (its size lives on in C[k].size): k_final's tile roots read
+    // (new label, segment start) of their final root in one round trip
+    for (int k = 0; k < K; k++) { C[k].offset = off; rsize[C[k].comp] = off; off += C[k].size; }
     a.counters[f * 8 + 1] = K;
     if (a.n_clusters) a.n_clusters[f] = K;
     // the launch's cluster list for k_median (order irrelevant): workgroups are then launched per cluster, not per frame
@@ -1185,6 +1211,7 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
 #else
 #define FINAL_ST(p, v) (*(p) = (v))
 #endif
+constexpr int kFinalEarly = 32;   // dynamic pixels in a wave's rows from which its velocity / depth rows are fetched with the first round trip
 template <int TH, int NW, bool XY_FROM_Z>
 __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   constexpr int RPW = TH / NW;
@@ -1214,20 +1241,50 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
     rw[j] = (y < c.H) ? a.lroot[wo] : 0ull;
     par[j] = a.parent[fN + (size_t)yc * c.W + xc];
   }
-  // ---- tile roots: their parent entry names the final root (k_ccl_merge), whose record holds the new label ----
+  // ---- tile roots: their parent entry names the final root (k_ccl_merge), whose entries hold the new label (rkey, k_select) and the
+  // start of the cluster's member segment (rsize, k_select); the tile root's own key entry holds its place inside that segment
+  // (k_ccl_merge).  ONE round trip, three independent gathers; the cell's counter starts at the first slot of its members, so that
+  // the LDS atomics below hand out absolute slots — no global cursor atomic, no second barrier (round 4: four dependent round
+  // trips and three barriers per tile) ----
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
     if ((rw[j] >> lane) & 1ull) {
       const int cell = (r0 + j) * 64 + lane;
-      nlmap[cell] = MOD_CHECK(a, par[j] >= 0 && (size_t)par[j] < N, 5) ? a.rkey[fN + par[j]] : -1;
-      lcount[cell] = 0;
+      const int p = (y0 + r0 + j) * c.W + x;
+      int lab = -1, first = 0;
+      if (MOD_CHECK(a, par[j] >= 0 && (size_t)par[j] < N, 5)) {
+        const int fr = par[j];
+        lab = a.rkey[fN + fr];
+        const int seg = a.rsize[fN + fr];
+        const int own = a.rkey[fN + p];
+        first = seg + (fr == p ? 0 : own);
+      }
+      nlmap[cell] = lab;
+      lcount[cell] = first;
     }
   }
+  // velocity (for the ||v|| bits) and depth (for the bounding box) of the wave's rows: tiles with this many dynamic pixels nearly
+  // always hold members of a surviving cluster — their loads leave with the gathers above instead of after them
+  float vx[RPW], vy[RPW], vz[RPW], px[RPW], py[RPW], pz[RPW];
+  int ndyn = 0;
+#pragma unroll
+  for (int j = 0; j < RPW; j++) ndyn += __popcll((unsigned long long)mw[j]);
+  const bool early = ndyn >= kFinalEarly;                            // wave-uniform
+  auto load_members = [&]() {
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const size_t gp = fN + (size_t)min(y0 + r0 + j, c.H - 1) * c.W + xc;
+      vx[j] = a.vx[gp]; vy[j] = a.vy[gp]; vz[j] = a.vz[gp];
+      pz[j] = a.z[gp];
+      if (!XY_FROM_Z) { px[j] = a.x[gp]; py[j] = a.y[gp]; }
+    }
+  };
+  if (early) load_members();
   lds_barrier();
   // ---- labels ----
   const float invW = 1.0f / (float)c.W;
   const int tile0 = y0 * c.W + x0;
-  int nl[RPW], cell[RPW], rank[RPW];
+  int nl[RPW], cell[RPW], slot[RPW];
   bool any_member = false;
 #pragma unroll
   for (int j = 0; j < RPW; j++) {
@@ -1242,18 +1299,19 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
     if (!MOD_CHECK(a, cl >= 0 && cl < TH * 64 && (!dyn || isroot || (d >= 0 && d - ly * c.W < 64)), 6)) cl = 0;
     int l = dyn ? nlmap[cl] : -1;
     if (!MOD_CHECK(a, l >= -1 && l < a.max_objects, 7)) l = -1;
-    nl[j] = l; cell[j] = cl; rank[j] = 0;
+    nl[j] = l; cell[j] = cl; slot[j] = 0;
     if (a.labels && y < c.H && x < c.W) FINAL_ST(&a.labels[fN + (size_t)y * c.W + x], l);
     any_member = any_member || (__ballot(l >= 0) != 0);
   }
-  // ---- members: counted per tile root in LDS ----
   if (any_member) {                                  // wave-uniform
+    if (!early) load_members();
+    // ---- members: slots handed out per tile root in LDS ----
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       const int l = nl[j], cl = cell[j];
       const uint64_t mb = __ballot(l >= 0);
       if (mb == 0) continue;                         // wave-uniform
-      // lanes that share the first member's tile root reserve ranks with one LDS atomic; stragglers use their own
+      // lanes that share the first member's tile root reserve their slots with one LDS atomic; stragglers use their own
       const int lead = __ffsll((unsigned long long)mb) - 1;
       const int c0 = __builtin_amdgcn_readlane(cl, lead);
       const bool grp = l >= 0 && cl == c0;
@@ -1261,19 +1319,8 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
       int base = 0;
       if (lane == lead) base = atomicAdd(&lcount[c0], __popcll((unsigned long long)gb));
       base = __builtin_amdgcn_readlane(base, lead);
-      if (grp) rank[j] = base + __popcll((unsigned long long)(gb & ((1ull << lane) - 1ull)));
-      else if (l >= 0) rank[j] = atomicAdd(&lcount[cl], 1);
-    }
-  }
-  // velocity (for the ||v|| bits) and coordinates (for the bounding box) of the wave's members, in flight across the barriers
-  float vx[RPW], vy[RPW], vz[RPW], px[RPW], py[RPW], pz[RPW];
-  if (any_member) {
-#pragma unroll
-    for (int j = 0; j < RPW; j++) {
-      const size_t gp = fN + (size_t)min(y0 + r0 + j, c.H - 1) * c.W + xc;
-      vx[j] = a.vx[gp]; vy[j] = a.vy[gp]; vz[j] = a.vz[gp];
-      pz[j] = a.z[gp];
-      if (!XY_FROM_Z) { px[j] = a.x[gp]; py[j] = a.y[gp]; }
+      if (grp) slot[j] = base + __popcll((unsigned long long)(gb & ((1ull << lane) - 1ull)));
+      else if (l >= 0) slot[j] = atomicAdd(&lcount[cl], 1);
     }
     if (XY_FROM_Z) {
       const double rx = c.rayx[xc];
@@ -1284,27 +1331,12 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
         py[j] = (float)(c.rayy[min(y0 + r0 + j, c.H - 1)] * zd);
       }
     }
-  }
-  lds_barrier();
-  // ---- one cursor atomic per tile root with members ----
-#pragma unroll
-  for (int j = 0; j < RPW; j++) {
-    if ((rw[j] >> lane) & 1ull) {
-      const int cl = (r0 + j) * 64 + lane;
-      const int l = nlmap[cl], cnt = lcount[cl];
-      if (l >= 0 && cnt > 0)
-        lcount[cl] = a.clusters[(size_t)f * a.max_objects + l].offset + atomicAdd(&a.cursors[(size_t)f * a.max_objects + l], cnt);
-    }
-  }
-  lds_barrier();
-  if (any_member) {
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       if (nl[j] >= 0) {
-        const size_t slot = fN + lcount[cell[j]] + rank[j];
-        if (MOD_CHECK(a, lcount[cell[j]] >= 0 && rank[j] >= 0 && (size_t)(lcount[cell[j]] + rank[j]) < N, 8)) {
-          a.mbits[slot] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
-          a.mpix[slot] = (uint32_t)((y0 + r0 + j) * c.W + x);
+        if (MOD_CHECK(a, slot[j] >= 0 && (size_t)slot[j] < N, 8)) {
+          a.mbits[fN + slot[j]] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
+          a.mpix[fN + slot[j]] = (uint32_t)((y0 + r0 + j) * c.W + x);
         }
       }
     }
@@ -1541,7 +1573,7 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     {
       bool anynan = false;
       for (int d = 0; d < 3; d++) anynan = anynan || isnan(ord2f(rec.w[d])) || isnan(ord2f(~rec.w[3 + d]));
-      if (anynan) {                                  // block-uniform
+      if (anynan && a.x && a.y) {                    // block-uniform (a fused call without x, y planes cannot get here: its members' coordinates are finite)
         const float *pl[3] = {a.x + (size_t)f * N, a.y + (size_t)f * N, a.z + (size_t)f * N};
         for (int d = 0; d < 3; d++) {
           if (tid == 0) { s_cnt = 0u; s_bin = 0xffffffffu; s_rem = 0u; s_val = 0u; }   // last NaN key+1, min, max, survivors

@@ -12,6 +12,8 @@ struct SfArgs {
   const FrameConst *fc;               // [F] device
   int32_t *tilehdr;                   // [F][tiles][2] or null: header word 0 of every cluster tile with a dynamic pixel is set to 1
   int32_t tile_rows, tiles_x, tiles_per_frame;   // (zeroed by the caller beforehand); tile = 64 x tile_rows pixels
+  float2 *zrange;                     // [F][H][mask_words] or null: (smallest, largest) depth z of the DYNAMIC pixels of every non-zero mask
+                                      // word, written with the word (k_ccl_bits decides one-class tiles from it without loading a depth row)
   unsigned long long *dbg;            // the context's diagnostic counters (checked build: index assertion 16), unused by a product build
 };
 
@@ -19,19 +21,22 @@ struct SfArgs {
 struct ClArgs {
   const float *x, *y, *z, *vx, *vy, *vz;  // input planes [F][H][W]
   const uint64_t *mask;       // [F][H][mask_words] dynamic bits
+  const float2 *zrange;       // [F][H][mask_words] depth range of the dynamic pixels of every NON-ZERO mask word (the fused scene-flow
+                              // kernel's epilogue writes it with the word; entries of zero words are undefined), or null: a caller's cloud
   uint64_t *lroot;            // [F][H][mask_words] pixel is the root of a tile-local component (owns a partial record)
   int32_t *parent;            // [F][N] union-find parents (only dynamic entries are ever touched)
   int32_t *rootlist;          // [F][N] pixel indices of the final roots (aliases `mpix`, dead before k_final)
   int32_t *labels;            // [F][N] output plane; used as the root/code plane in between
-  int32_t *rsize;             // [F][N] member count of the component rooted at this pixel (sparse: only root entries are touched)
-  int32_t *rkey;              // [F][N] its first_edge_key; after k_select the new label of a final root, or -1
+  int32_t *rsize;             // [F][N] member count of the component rooted at this pixel (sparse: only root entries are touched); after
+                              // k_select, at the final root of a surviving cluster: start of the cluster's member segment
+  int32_t *rkey;              // [F][N] its first_edge_key; after k_ccl_merge, at a tile root that is not final: its members' place inside the
+                              // component's member segment; after k_select, at a final root: the new label, or -1
   ClusterBox *cbox;           // [F][max_objects] bounding boxes of the surviving clusters (k_select init, k_final atomics)
   int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects; of frame 0 also (counts of the whole launch): 3 cursor into
                               // `tilelist`, 4 its length, 5 k_median's cursor into `worklist`, 6 its length, 7 length of `tielist`
   ClusterInfo *clusters;      // [F][max_objects]
   uint32_t *mbits;            // [F][N] ||v|| bit patterns of the members, grouped per cluster (SoA with mpix)
   uint32_t *mpix;             // [F][N] pixel index of each member
-  int32_t *cursors;           // [F][max_objects] fill cursors of the member segments
   uint32_t *worklist;         // [F * max_objects] frame * max_objects + cluster of every cluster of the launch; count in counters[6]
   uint32_t *tielist;          // [F * max_objects] the clusters k_median flagged ambiguous;                count in counters[7]
   void *objects;              // [F][max_objects] ModObject

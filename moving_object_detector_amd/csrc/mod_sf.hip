@@ -24,13 +24,13 @@ struct Buffers {
   double *rayx = nullptr, *rayy = nullptr;
   FrameConst *fc = nullptr;                 // [maxF]
   uint64_t *mask = nullptr, *lroot = nullptr;
+  float2 *zrange = nullptr;                 // [maxF][H][mask_words] depth range of the dynamic pixels of each mask word (fused path)
   int32_t *parent = nullptr;
   int32_t *rsize = nullptr, *rkey = nullptr;
   ClusterBox *cbox = nullptr;
   int32_t *counters = nullptr;
   ClusterInfo *clusters = nullptr;          // 2 x [maxF][max_objects]
   uint32_t *mbits = nullptr, *mpix = nullptr;
-  int32_t *cursors = nullptr;
   uint32_t *worklist = nullptr;   // [2][F * max_objects]: all clusters of a launch, then the ambiguous ones
   unsigned long long *dbg = nullptr;
   uint2 *requests = nullptr;
@@ -263,9 +263,12 @@ int check_batch(ModContext *c, const ModFrameBatch *in) {
   return MOD_OK;
 }
 
-int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask, bool tile_flags) {
-  if (!out || !out->x || !out->y || !out->z || !out->vx || !out->vy || !out->vz)
-    return fail(c, MOD_ERR_INVALID_ARGUMENT, "scene-flow output planes x,y,z,vx,vy,vz are required");
+int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask, bool tile_flags, bool xy_optional) {
+  if (!out || !out->z || !out->vx || !out->vy || !out->vz)
+    return fail(c, MOD_ERR_INVALID_ARGUMENT, "scene-flow output planes z,vx,vy,vz are required");
+  // x and y: both or neither; neither only where the call says so (mod_process_dev: the cluster stage recomputes them from z)
+  if ((out->x == nullptr) != (out->y == nullptr) || (!out->x && !xy_optional))
+    return fail(c, MOD_ERR_INVALID_ARGUMENT, xy_optional ? "scene-flow output planes x and y: pass both or neither" : "scene-flow output planes x,y,z,vx,vy,vz are required");
   int rc = upload_frame_consts(c, in);
   if (rc) return rc;
   SfArgs a;
@@ -273,11 +276,12 @@ int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPla
   a.x = out->x; a.y = out->y; a.z = out->z; a.vx = out->vx; a.vy = out->vy; a.vz = out->vz;
   a.mask = mask; a.aos = (float4 *)out->cloud_aos; a.depth = out->depth; a.sflow = out->static_flow;
   a.fc = c->b.fc;
-  a.tilehdr = nullptr; a.tile_rows = ccl_tile_rows(); a.tiles_x = c->dc.mask_words;
+  a.tilehdr = nullptr; a.zrange = nullptr; a.tile_rows = ccl_tile_rows(); a.tiles_x = c->dc.mask_words;
   a.tiles_per_frame = c->dc.mask_words * ((c->dc.H + ccl_tile_rows() - 1) / ccl_tile_rows());
   a.dbg = c->b.dbg;
   if (tile_flags && mask) {      // the clustering follows: the kernel's epilogue also marks the cluster tiles that hold a dynamic pixel
     a.tilehdr = c->b.tilehdr;
+    a.zrange = c->b.zrange;        // ... and leaves the depth range of every non-zero mask word's dynamic pixels for the tile stage
     HIP_TRY(c, hipMemsetAsync(c->b.tilehdr, 0, sizeof(int32_t) * 2 * (size_t)a.tiles_per_frame * in->frames, c->stream));
   }
   {
@@ -290,15 +294,16 @@ int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPla
 
 int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready, bool flags_ready,
                 const ModClusterOut *out) {
-  if (!pl || !pl->x || !pl->y || !pl->z || !pl->vx || !pl->vy || !pl->vz)
+  // flags_ready: the planes are this call's own scene-flow output (mod_process_dev), where x, y are functions of z and may be absent
+  if (!pl || !pl->z || !pl->vx || !pl->vy || !pl->vz || (!flags_ready && (!pl->x || !pl->y)))
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster input planes x,y,z,vx,vy,vz are required");
   if (!out || !out->objects || !out->n_objects)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster outputs objects, n_objects are required");
   ClArgs a;
   a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
-  a.mask = mask; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.mpix;
+  a.mask = mask; a.zrange = flags_ready ? c->b.zrange : nullptr; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.mpix;
   a.labels = out->labels; a.rsize = c->b.rsize; a.rkey = c->b.rkey; a.cbox = c->b.cbox; a.counters = c->b.counters; a.clusters = c->b.clusters;
-  a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.cursors = c->b.cursors; a.worklist = c->b.worklist; a.tielist = c->b.worklist + (size_t)c->cfg.max_frames * c->max_objects;
+  a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.worklist = c->b.worklist; a.tielist = c->b.worklist + (size_t)c->cfg.max_frames * c->max_objects;
   a.objects = out->objects; a.n_objects = out->n_objects;
   a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
   a.xy_from_z = flags_ready ? 1 : 0;                  // only mod_process_dev's fused path hands over its own scene-flow planes
@@ -358,6 +363,7 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   ok &= dalloc(&c->b.fc, F) == hipSuccess;
   ok &= dalloc(&c->b.mask, mw) == hipSuccess;
   ok &= dalloc(&c->b.lroot, mw) == hipSuccess;
+  ok &= dalloc(&c->b.zrange, mw) == hipSuccess;
   ok &= dalloc(&c->b.parent, (size_t)F * N) == hipSuccess;
   ok &= dalloc(&c->b.rsize, (size_t)F * N) == hipSuccess;   // 4 + 4 B per pixel of address space, touched only at roots
   ok &= dalloc(&c->b.rkey, (size_t)F * N) == hipSuccess;
@@ -366,7 +372,6 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   ok &= dalloc(&c->b.clusters, (size_t)2 * F * c->max_objects) == hipSuccess;
   ok &= dalloc(&c->b.mbits, (size_t)F * N) == hipSuccess;
   ok &= dalloc(&c->b.mpix, (size_t)F * N) == hipSuccess;
-  ok &= dalloc(&c->b.cursors, (size_t)F * c->max_objects) == hipSuccess;
   ok &= dalloc(&c->b.worklist, (size_t)2 * F * c->max_objects) == hipSuccess;
   {
     const size_t tiles = (size_t)c->max_mask_words * ((cfg->max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
@@ -390,8 +395,8 @@ void mod_destroy(ModContext *c) {
   if (!c) return;
   (void)hipStreamSynchronize(c->stream);
   Buffers &b = c->b;
-  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.parent, b.rsize, b.rkey, b.cbox, b.counters, b.clusters, b.mbits, b.mpix,
-                 b.cursors, b.worklist, b.dbg, b.requests, b.tilehdr, b.tilelist, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects, b.sgm_census, b.sgm_maps, b.sgm_S};
+  void *dev[] = {b.rayx, b.rayy, b.fc, b.mask, b.lroot, b.zrange, b.parent, b.rsize, b.rkey, b.cbox, b.counters, b.clusters, b.mbits, b.mpix,
+                 b.worklist, b.dbg, b.requests, b.tilehdr, b.tilelist, b.h_dnow, b.h_dprev, b.h_flow, b.h_planes, b.h_aos, b.h_labels, b.h_nobj, b.h_objects, b.sgm_census, b.sgm_maps, b.sgm_S};
   for (void *p : dev) if (p) (void)hipFree(p);
   for (int i = 0; i < kRing; i++) {
     if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
@@ -500,7 +505,15 @@ static int depth_on_skip(ModContext *c, int skip, const ModFrameBatch *in, const
 int mod_scene_flow_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out) {
   int rc = check_batch(c, in);
   if (rc) return depth_on_skip(c, rc, in, out);
-  return run_scene_flow(c, in, out, out ? out->dynamic_mask : nullptr, false);
+  return run_scene_flow(c, in, out, out ? out->dynamic_mask : nullptr, false, false);
+}
+
+// the scene-flow stage of the host entry points: their SoA planes are internal staging that no caller sees (the cloud leaves as
+// 32-byte records straight from the kernel's registers), so the x and y planes are not written at all
+static int scene_flow_staged(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out) {
+  int rc = check_batch(c, in);
+  if (rc) return depth_on_skip(c, rc, in, out);
+  return run_scene_flow(c, in, out, out->dynamic_mask, false, true);
 }
 
 int mod_depth_image_dev(ModContext *c, int32_t frames, const float *disparity_now, float *depth) {
@@ -533,7 +546,7 @@ int mod_process_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPl
   int rc = check_batch(c, in);
   if (rc) return depth_on_skip(c, rc, in, pl);
   uint64_t *mask = (pl && pl->dynamic_mask) ? pl->dynamic_mask : c->b.mask;
-  rc = run_scene_flow(c, in, pl, mask, true);
+  rc = run_scene_flow(c, in, pl, mask, true, true);
   if (rc) return rc;
   return run_cluster(c, in->frames, pl, mask, true, true, out);
 }
@@ -738,11 +751,13 @@ static int ensure_host_staging(ModContext *c) {
   return MOD_OK;
 }
 
-static void staged_planes(ModContext *c, ModSceneFlowPlanes *pl) {
+// xy: the x and y planes too (a caller's cloud unpacked for the clusterer); the fused host paths leave them out (scene_flow_staged)
+static void staged_planes(ModContext *c, ModSceneFlowPlanes *pl, bool xy) {
   const size_t N = (size_t)c->dc.W * c->dc.H;
   float *p = c->b.h_planes;
   memset(pl, 0, sizeof(*pl));
-  pl->x = p; pl->y = p + N; pl->z = p + 2 * N; pl->vx = p + 3 * N; pl->vy = p + 4 * N; pl->vz = p + 5 * N;
+  if (xy) { pl->x = p; pl->y = p + N; }
+  pl->z = p + 2 * N; pl->vx = p + 3 * N; pl->vy = p + 4 * N; pl->vz = p + 5 * N;
 }
 
 static int fetch_cluster_results(ModContext *c, int32_t *labels, ModObject *objects, int32_t max_objects, int32_t *n_objects) {
@@ -781,14 +796,14 @@ int mod_process_frame_host(ModContext *c, const float *disparity_now, const floa
   in.frames = 1; in.disparity_now = b.h_dnow; in.disparity_prev = b.h_dprev; in.flow = b.h_flow;
   in.transforms = transform; in.dt = &dt;
   ModSceneFlowPlanes pl;
-  staged_planes(c, &pl);
+  staged_planes(c, &pl, false);
   pl.cloud_aos = cloud_aos ? b.h_aos : nullptr;
   ModClusterOut out{};
   out.labels = labels ? b.h_labels : nullptr; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
-  // no cluster output asked for (neither labels nor objects): the scene-flow stage alone — a constructor whose moving objects
-  // nobody takes does not cluster (the reference's constructor never does; its clusterer is a node of its own)
-  const bool cluster = labels || objects;
-  rc = cluster ? mod_process_dev(c, &in, &pl, &out) : mod_scene_flow_dev(c, &in, &pl);
+  // no cluster output asked for (neither labels nor objects nor their count): the scene-flow stage alone — a constructor whose
+  // moving objects nobody takes does not cluster (the reference's constructor never does; its clusterer is a node of its own)
+  const bool cluster = labels || objects || n_objects;
+  rc = cluster ? mod_process_dev(c, &in, &pl, &out) : scene_flow_staged(c, &in, &pl);
   if (rc) return rc;
   if (cloud_aos) HIP_TRY(c, hipMemcpyAsync(cloud_aos, b.h_aos, 32 * N, hipMemcpyDeviceToHost, c->stream));
   if (!cluster) { HIP_TRY(c, hipStreamSynchronize(c->stream)); return MOD_OK; }
@@ -828,9 +843,9 @@ int mod_static_flow_host(ModContext *c, const float *disparity_prev, const ModTr
   const double dt = 1.0;
   in.frames = 1; in.disparity_now = b.h_dprev; in.disparity_prev = b.h_dprev; in.flow = b.h_flow; in.transforms = transform; in.dt = &dt;
   ModSceneFlowPlanes pl;
-  staged_planes(c, &pl);
+  staged_planes(c, &pl, false);
   pl.static_flow = reinterpret_cast<float *>(b.h_aos);      // 8 of the staging cloud's 32 bytes per pixel
-  if ((rc = mod_scene_flow_dev(c, &in, &pl))) return rc;
+  if ((rc = scene_flow_staged(c, &in, &pl))) return rc;
   HIP_TRY(c, hipMemcpyAsync(static_flow, b.h_aos, 8 * N, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return MOD_OK;
@@ -864,7 +879,7 @@ int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int3
   HIP_TRY(c, hipMemcpy2DAsync(b.h_aos, (size_t)32 * width, cloud, (size_t)row_step, (size_t)32 * width, (size_t)height,
                               hipMemcpyHostToDevice, c->stream));
   ModSceneFlowPlanes pl;
-  staged_planes(c, &pl);
+  staged_planes(c, &pl, true);
   launch_unpack((size_t)width * height, b.h_aos, pl.x, pl.y, pl.z, pl.vx, pl.vy, pl.vz, c->stream);
   HIP_TRY(c, hipGetLastError());
   ModClusterOut out{};
@@ -885,7 +900,7 @@ static int ensure_pipe(ModContext *c) {
   for (int i = 0; i < MOD_PIPELINE_DEPTH; i++) {
     HIP_TRY(c, dalloc(&p.dprev[i], N));
     HIP_TRY(c, dalloc(&p.flow[i], 2 * N));
-    HIP_TRY(c, dalloc(&p.planes[i], 6 * N));
+    HIP_TRY(c, dalloc(&p.planes[i], 4 * N));
     if (!p.aos[i]) HIP_TRY(c, hipMalloc(&p.aos[i], 32 * N));
     HIP_TRY(c, dalloc(&p.labels[i], N));
     HIP_TRY(c, dalloc(&p.nobj[i], 8));
@@ -937,13 +952,13 @@ int mod_submit_frame_host(ModContext *c, const float *disparity_now, const float
   in.flow = p.flow[slot]; in.transforms = transform; in.dt = &dt;
   ModSceneFlowPlanes pl;
   memset(&pl, 0, sizeof(pl));
-  float *q = p.planes[slot];
-  pl.x = q; pl.y = q + N; pl.z = q + 2 * N; pl.vx = q + 3 * N; pl.vy = q + 4 * N; pl.vz = q + 5 * N;
+  float *q = p.planes[slot];                 // z, vx, vy, vz for the cluster stage; no x, y planes (see scene_flow_staged)
+  pl.z = q; pl.vx = q + N; pl.vy = q + 2 * N; pl.vz = q + 3 * N;
   pl.cloud_aos = cloud_aos ? p.aos[slot] : nullptr;
   ModClusterOut out{};
   out.labels = labels ? p.labels[slot] : nullptr; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
   const bool cluster = labels || objects;     // neither asked for: the scene-flow stage alone (see mod_process_frame_host)
-  if ((rc = cluster ? mod_process_dev(c, &in, &pl, &out) : mod_scene_flow_dev(c, &in, &pl))) return rc;
+  if ((rc = cluster ? mod_process_dev(c, &in, &pl, &out) : scene_flow_staged(c, &in, &pl))) return rc;
   HIP_TRY(c, hipEventRecord(p.ev_done[slot], c->stream));
   // results: their own stream
   HIP_TRY(c, hipStreamWaitEvent(p.d2h, p.ev_done[slot], 0));
@@ -1007,13 +1022,13 @@ int mod_submit_stereo_host(ModContext *c, const uint8_t *left, const uint8_t *ri
   in.flow = p.flow[slot]; in.transforms = transform; in.dt = &dt;
   ModSceneFlowPlanes pl;
   memset(&pl, 0, sizeof(pl));
-  float *q = p.planes[slot];
-  pl.x = q; pl.y = q + N; pl.z = q + 2 * N; pl.vx = q + 3 * N; pl.vy = q + 4 * N; pl.vz = q + 5 * N;
+  float *q = p.planes[slot];                 // z, vx, vy, vz for the cluster stage; no x, y planes (see scene_flow_staged)
+  pl.z = q; pl.vx = q + N; pl.vy = q + 2 * N; pl.vz = q + 3 * N;
   pl.cloud_aos = cloud_aos ? p.aos[slot] : nullptr;
   ModClusterOut out{};
   out.labels = labels ? p.labels[slot] : nullptr; out.objects = p.objects[slot]; out.n_objects = p.nobj[slot]; out.n_clusters = p.nobj[slot] + 1;
   const bool cluster = labels || objects;     // neither asked for: the scene-flow stage alone (see mod_process_frame_host)
-  if ((rc = cluster ? mod_process_dev(c, &in, &pl, &out) : mod_scene_flow_dev(c, &in, &pl))) return rc;
+  if ((rc = cluster ? mod_process_dev(c, &in, &pl, &out) : scene_flow_staged(c, &in, &pl))) return rc;
   HIP_TRY(c, hipEventRecord(p.ev_done[slot], c->stream));
   HIP_TRY(c, hipStreamWaitEvent(p.d2h, p.ev_done[slot], 0));
   if (cluster) HIP_TRY(c, hipMemcpyAsync(p.h_n[slot], p.nobj[slot], sizeof(int32_t), hipMemcpyDeviceToHost, p.d2h));
@@ -1094,11 +1109,11 @@ int mod_memcpy_d2h(ModContext *c, void *h, const void *d, uint64_t bytes) {
 
 #if defined(MOD_PHASE_COUNTERS) || defined(MOD_ABLATION) || defined(MOD_CHECKED)
 // diagnostic builds only (declared in mod_sf_debug.h; a product build does not export them)
-// copy an internal buffer to the host (0 members, 1 clusters, 2 counters, 3 cursors)
+// copy an internal buffer to the host (0 member norms, 4 member pixels, 1 clusters, 2 counters)
 int mod_debug_read(ModContext *c, int which, void *dst, unsigned long long bytes) {
   if (!c || !dst) return MOD_ERR_INVALID_ARGUMENT;
   const void *src = which == 0 ? (const void *)c->b.mbits : which == 4 ? (const void *)c->b.mpix : which == 1 ? (const void *)c->b.clusters
-                  : which == 2 ? (const void *)c->b.counters : (const void *)c->b.cursors;
+                  : (const void *)c->b.counters;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return MOD_OK;

@@ -6,7 +6,7 @@
 #include "../../include/mod_sf.h"
 extern "C" {
 #pragma GCC visibility push(default)
-// copy an internal scratch buffer to the host: 0 member norms, 4 member pixels, 1 cluster table, 2 counters, 3 cursors
+// copy an internal scratch buffer to the host: 0 member norms, 4 member pixels, 1 cluster table, 2 counters
 int mod_debug_read(ModContext *ctx, int which, void *dst, unsigned long long bytes);
 // 64 cycle / event counters written by the instrumented kernels; reading resets them
 int mod_debug_counters(ModContext *ctx, unsigned long long *out64);

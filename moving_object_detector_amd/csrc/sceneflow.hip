@@ -186,6 +186,25 @@ __device__ __forceinline__ uint64_t nibbles_to_word(uint32_t nib, int lane) {
   return (uint64_t)v | ((uint64_t)hi << 32);
 }
 
+// Depth range of the DYNAMIC pixels of a mask word, stored next to the word (SfArgs.zrange): a dynamic pixel has a finite z (it is
+// valid: x = ray * z is neither NaN nor inf), everything else enters as a quiet NaN, which v_min / v_max pass over.  The plain
+// instructions: fminf / fmaxf would put a canonicalising v_max x, x in front of every operand.
+__device__ __forceinline__ float sf_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float sf_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#define SF_DPPF(v, ctrl) __uint_as_float(MOD_DPP(__float_as_uint(v), ctrl))
+// min / max over the 16 lanes of a DPP row (= the 64 pixels of one mask word in k_scene_flow_v4): every lane of the row ends with the result
+__device__ __forceinline__ void row16_minmax(float &mn, float &mx) {
+  mn = sf_min(mn, SF_DPPF(mn, 0xB1)); mx = sf_max(mx, SF_DPPF(mx, 0xB1));      // quad_perm [1,0,3,2]
+  mn = sf_min(mn, SF_DPPF(mn, 0x4E)); mx = sf_max(mx, SF_DPPF(mx, 0x4E));      // quad_perm [2,3,0,1]
+  mn = sf_min(mn, SF_DPPF(mn, 0x141)); mx = sf_max(mx, SF_DPPF(mx, 0x141));    // row_half_mirror
+  mn = sf_min(mn, SF_DPPF(mn, 0x140)); mx = sf_max(mx, SF_DPPF(mx, 0x140));    // row_mirror
+}
+// the same over groups of G consecutive lanes (the narrower kernels: 32 lanes or the whole wave per mask word); not on the hot path
+template <int G> __device__ __forceinline__ void group_minmax(float &mn, float &mx) {
+#pragma unroll
+  for (int o = 1; o < G; o <<= 1) { mn = sf_min(mn, __shfl_xor(mn, o)); mx = sf_max(mx, __shfl_xor(mx, o)); }
+}
+
 // Addressing: a wave-uniform 64-bit base (frame plane, in SGPRs) plus a 32-bit byte offset per lane, which is the
 // `global_load/store v, v_off, s[base]` form — no 64-bit address arithmetic on the vector unit (the kernel is VALU-bound).
 // mod_set_camera guarantees W*H*32 < 2^32.
@@ -218,7 +237,7 @@ template <class T> __device__ __forceinline__ T karg(size_t off) {
 }
 constexpr size_t kSfArgsAt = (sizeof(DevCam) + alignof(SfArgs) - 1) / alignof(SfArgs) * alignof(SfArgs);   // k(DevCam c, SfArgs a)
 #define LATE_A(field) karg<decltype(SfArgs::field)>(kSfArgsAt + offsetof(SfArgs, field))
-// karg()/LATE_A are tied to the signature `k_scene_flow_v4(DevCam c, SfArgs a)`: by-value aggregates are laid out in the kernarg
+// karg()/LATE_A are tied to the signature `k_scene_flow_v4<XY>(DevCam c, SfArgs a)`: by-value aggregates are laid out in the kernarg
 // segment in declaration order at their natural alignment (code object v5: explicit arguments first, hidden ones after), i.e.
 // exactly like the members of the struct below.  A change of the signature or of either struct must change this too — a wrong
 // offset would store through garbage pointers.  The checked build also compares LATE_A(vx) with a.vx at run time (code 16).
@@ -227,6 +246,9 @@ static_assert(std::is_trivially_copyable<DevCam>::value && std::is_trivially_cop
 static_assert(alignof(DevCam) <= 8 && alignof(SfArgs) <= 8, "kernarg segment is 8-byte aligned per argument here");
 static_assert(kSfArgsAt == offsetof(SfKernargLayout, a), "SfArgs does not sit where karg() reads it");
 // Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
+// XY: the x and y planes are written (ModSceneFlowPlanes.x / .y given).  Two instances rather than a branch: the six-plane kernel's
+// instruction stream stays what it was (the kernel is sensitive to it: a wave-uniform `if (a.x)` around the two stores cost +1.6 %).
+template <bool XY>
 __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const int lane = threadIdx.x;                      // 0..63
   // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), and each XCD has its
@@ -261,6 +283,9 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   uint32_t nib = 0;
   uint64_t *out_mask = nullptr;
   int32_t *out_hdr = nullptr;
+  float2 *out_zr = nullptr;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  float zmn = qnan, zmx = qnan;                       // depth range of this thread's dynamic pixels
   if (inb) {
     const float *dprev_f = a.dprev + fN;
     const float4 dn = ld<float4>(a.dnow + fN, o4);
@@ -276,9 +301,13 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
     sf_stage1(c, fc, x0 + 1, y, dn.y, dp.y, fa.z, fa.w, rxa.y, ry, p1, s1);
     sf_stage1(c, fc, x0 + 2, y, dn.z, dp.z, fb.x, fb.y, rxb.x, ry, p2, s2);
     sf_stage1(c, fc, x0 + 3, y, dn.w, dp.w, fb.z, fb.w, rxb.y, ry, p3, s3);
-    // x, y, z are final after stage 1: their stores leave before the gathers come back
-    st_plane(a.x + fN, o4, p0.x, p1.x, p2.x, p3.x);
-    st_plane(a.y + fN, o4, p0.y, p1.y, p2.y, p3.y);
+    // x, y, z are final after stage 1: their stores leave before the gathers come back.  The x and y planes are optional (both or
+    // neither; wave-uniform): a caller that serves the moving objects alone — no ~scene_flow subscriber, scene_flow_constructor.cpp:141-142
+    // — does not pay their 8 B/px, and the cluster stage recomputes a member's x, y from z (k_final XY_FROM_Z)
+    if (XY) {
+      st_plane(a.x + fN, o4, p0.x, p1.x, p2.x, p3.x);
+      st_plane(a.y + fN, o4, p0.y, p1.y, p2.y, p3.y);
+    }
     st_plane(a.z + fN, o4, p0.z, p1.z, p2.z, p3.z);
     // the four gathers (and their ray-table reads) leave together: unconditional loads at in-image targets; so do the scalar
     // loads of the output pointers that are needed from here on
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
 #endif
     float4 *const out_aos = LATE_A(aos);
     float *const out_depth = LATE_A(depth), *const out_sflow = LATE_A(sflow);
-    out_mask = LATE_A(mask); out_hdr = LATE_A(tilehdr);
+    out_mask = LATE_A(mask); out_hdr = LATE_A(tilehdr); out_zr = LATE_A(zrange);
     const uint32_t W = (uint32_t)c.W;
     const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
     const float g1 = ld<float>(dprev_f, ((uint32_t)s1.py * W + (uint32_t)s1.px) * 4u);
@@ -329,14 +358,24 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
       st(out_sflow + 2 * fN, o8 + 16u, make_float4(p2.s0, p2.s1, p3.s0, p3.s1));
     }
     nib = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u) | (p2.dyn ? 4u : 0u) | (p3.dyn ? 8u : 0u);
+    if (__any(nib != 0u)) {                                  // wave-uniform: few waves of a street scene hold a dynamic pixel
+      // a dynamic pixel is valid, so its z IS st.zn — which stage 2b kept alive anyway (p.z would be four more registers held since stage 1)
+      const float z0 = p0.dyn ? s0.zn : qnan, z1 = p1.dyn ? s1.zn : qnan, z2 = p2.dyn ? s2.zn : qnan, z3 = p3.dyn ? s3.zn : qnan;
+      zmn = sf_min(sf_min(z0, z1), sf_min(z2, z3)); zmx = sf_max(sf_max(z0, z1), sf_max(z2, z3));
+    }
   }
-  if (!inb) { out_mask = LATE_A(mask); out_hdr = LATE_A(tilehdr); }
+  if (!inb) { out_mask = LATE_A(mask); out_hdr = LATE_A(tilehdr); out_zr = LATE_A(zrange); }
   if (out_mask) {   // wave-uniform branch; all 64 lanes take part in the shuffles
     const uint64_t w = nibbles_to_word(nib, lane);
     const int word = (bx * 64 + lane) / 16;                  // (x0 / 64)
+    // In-process A/B of this epilogue addition (round 5, 512 pairs, 8 alternations): no ranges 3.424 ms, the store alone 3.417, the
+    // min / max alone 3.443, both 3.441 against 3.434 for round 4's kernel — inside the +-0.01 ms of the method; the tile stage saves 0.033 ms.
+    if (out_zr && __any(nib != 0u)) row16_minmax(zmn, zmx);  // wave-uniform: the clustering follows and the wave holds a dynamic pixel
     if ((lane & 15) == 0 && y < c.H && word < c.mask_words) {
-      out_mask[((size_t)f * c.H + y) * c.mask_words + word] = w;
+      const size_t wo = ((size_t)f * c.H + y) * c.mask_words + word;
+      out_mask[wo] = w;
       if (out_hdr && w) out_hdr[((size_t)f * LATE_A(tiles_per_frame) + (size_t)(y / LATE_A(tile_rows)) * LATE_A(tiles_x) + word) * 2] = 1;   // benign race: every writer stores 1
+      if (out_zr && w) out_zr[wo] = make_float2(zmn, zmx);   // only non-zero words have a range; k_ccl_bits reads no other
     }
   }
 }
@@ -355,6 +394,8 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
   const uint32_t o4 = pix * 4u, o8 = pix * 8u;
   const FrameConst fc = a.fc[f];
   uint32_t two = 0;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  float zmn = qnan, zmx = qnan;
   if (inb) {
     const float *dprev_f = a.dprev + fN;
     const float2 dn = ld<float2>(a.dnow + fN, o4);
@@ -366,8 +407,10 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
     PxState s0, s1;
     sf_stage1(c, fc, x0 + 0, y, dn.x, dp.x, fl.x, fl.y, rx.x, ry, p0, s0);
     sf_stage1(c, fc, x0 + 1, y, dn.y, dp.y, fl.z, fl.w, rx.y, ry, p1, s1);
-    st(a.x + fN, o4, make_float2(p0.x, p1.x));       // final after stage 1: out before the gathers come back
-    st(a.y + fN, o4, make_float2(p0.y, p1.y));
+    if (a.x) {                                       // final after stage 1: out before the gathers come back; x, y optional
+      st(a.x + fN, o4, make_float2(p0.x, p1.x));
+      st(a.y + fN, o4, make_float2(p0.y, p1.y));
+    }
     st(a.z + fN, o4, make_float2(p0.z, p1.z));
     const uint32_t W = (uint32_t)c.W;
     const float g0 = ld<float>(dprev_f, ((uint32_t)s0.py * W + (uint32_t)s0.px) * 4u);
@@ -393,16 +436,20 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
     if (a.depth) st(a.depth + fN, o4, make_float2(p0.depth, p1.depth));
     if (a.sflow) st(a.sflow + 2 * fN, o8, make_float4(p0.s0, p0.s1, p1.s0, p1.s1));
     two = (p0.dyn ? 1u : 0u) | (p1.dyn ? 2u : 0u);
+    zmn = sf_min(p0.dyn ? p0.z : qnan, p1.dyn ? p1.z : qnan); zmx = sf_max(p0.dyn ? p0.z : qnan, p1.dyn ? p1.z : qnan);
   }
   if (a.mask) {   // wave-uniform branch; lanes 0..31 build word 2*blockIdx.x, lanes 32..63 the next one
     uint32_t v = two << (2 * (lane & 15));
     v |= __shfl_xor(v, 1); v |= __shfl_xor(v, 2); v |= __shfl_xor(v, 4); v |= __shfl_xor(v, 8);
     const uint32_t hi = __shfl_down(v, 16);
     const int word = blockIdx.x * 2 + (lane >> 5);
+    if (a.zrange) group_minmax<32>(zmn, zmx);
     if ((lane & 31) == 0 && y < c.H && word < c.mask_words) {
       const uint64_t wd = (uint64_t)v | ((uint64_t)hi << 32);
-      a.mask[((size_t)f * c.H + y) * c.mask_words + word] = wd;
+      const size_t wo = ((size_t)f * c.H + y) * c.mask_words + word;
+      a.mask[wo] = wd;
       if (a.tilehdr && wd) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + word) * 2] = 1;
+      if (a.zrange && wd) a.zrange[wo] = make_float2(zmn, zmx);
     }
   }
 }
@@ -418,20 +465,27 @@ __global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) {
   const size_t i = (size_t)f * N + (size_t)y * c.W + x;
   const FrameConst fc = a.fc[f];
   bool dyn = false;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  float zmn = qnan, zmx = qnan;
   if (inb) {
     Px p;
     sf_pixel(c, fc, a.dprev + (size_t)f * N, x, y, a.dnow[i], a.dprev[i], a.flow[2 * i], a.flow[2 * i + 1], c.rayx[x], c.rayy[y], p);
-    a.x[i] = p.x; a.y[i] = p.y; a.z[i] = p.z; a.vx[i] = p.vx; a.vy[i] = p.vy; a.vz[i] = p.vz;
+    if (a.x) { a.x[i] = p.x; a.y[i] = p.y; }
+    a.z[i] = p.z; a.vx[i] = p.vx; a.vy[i] = p.vy; a.vz[i] = p.vz;
     if (a.aos) { a.aos[2 * i] = make_float4(p.x, p.y, p.z, 0.f); a.aos[2 * i + 1] = make_float4(p.vx, p.vy, p.vz, 0.f); }
     if (a.depth) a.depth[i] = p.depth;
     if (a.sflow) { a.sflow[2 * i] = p.s0; a.sflow[2 * i + 1] = p.s1; }
     dyn = p.dyn;
+    zmn = zmx = dyn ? p.z : qnan;
   }
   if (a.mask) {
     const uint64_t w = __ballot(dyn);
+    if (a.zrange) group_minmax<64>(zmn, zmx);
     if (lane == 0 && y < c.H && blockIdx.x < (unsigned)c.mask_words) {
-      a.mask[((size_t)f * c.H + y) * c.mask_words + blockIdx.x] = w;
+      const size_t wo = ((size_t)f * c.H + y) * c.mask_words + blockIdx.x;
+      a.mask[wo] = w;
       if (a.tilehdr && w) a.tilehdr[((size_t)f * a.tiles_per_frame + (size_t)(y / a.tile_rows) * a.tiles_x + blockIdx.x) * 2] = 1;
+      if (a.zrange && w) a.zrange[wo] = make_float2(zmn, zmx);
     }
   }
 }
@@ -485,7 +539,8 @@ void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t
   dim3 block(64, 4, 1);
   if ((c.W & 3) == 0) {
     dim3 grid((c.W / 4 + 63) / 64, (c.H + 3) / 4, frames);
-    hipLaunchKernelGGL(k_scene_flow_v4, grid, block, 0, s, c, a);
+    if (a.x) hipLaunchKernelGGL(k_scene_flow_v4<true>, grid, block, 0, s, c, a);
+    else hipLaunchKernelGGL(k_scene_flow_v4<false>, grid, block, 0, s, c, a);
   } else if ((c.W & 1) == 0) {
     dim3 grid((c.W / 2 + 63) / 64, (c.H + 3) / 4, frames);
     hipLaunchKernelGGL(k_scene_flow_v2, grid, block, 0, s, c, a);

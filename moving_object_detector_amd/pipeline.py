@@ -95,14 +95,15 @@ class Context:
             pass
 
     # ---- buffers ----------------------------------------------------------------------------------------------
-    def workspace(self, frames: int, aos: bool = False, extras: bool = False, labels: bool = True) -> dict:
+    def workspace(self, frames: int, aos: bool = False, extras: bool = False, labels: bool = True, xy: bool = True) -> dict:
         """Output buffers for `frames` frames, allocated once and reused.  labels=False: no cluster-label plane (the reference
-        renders its cluster image only for subscribers, clusterer_nodelet.cpp:235-236)."""
-        key = (frames, self.height, self.width, aos, extras, labels)
+        renders its cluster image only for subscribers, clusterer_nodelet.cpp:235-236).  xy=False: process() hands the library no x / y
+        planes (nobody takes the cloud, scene_flow_constructor.cpp:141-142): the rows 0 and 1 of `planes` are then never written."""
+        key = (frames, self.height, self.width, aos, extras, labels, xy)
         if self._ws is not None and self._ws["key"] == key:
             return self._ws
         H, W, dev = self.height, self.width, self.device
-        ws = {"key": key}
+        ws = {"key": key, "xy": xy}
         per = frames * H * W                             # six planes from one block, bases staggered (see PLANE_STAGGER_BYTES)
         skew = PLANE_STAGGER_BYTES // 4
         ws["planes"] = torch.empty(6 * per + 5 * skew, dtype=torch.float32, device=dev).as_strided((6, frames, H, W), (per + skew, H * W, W, 1))
@@ -121,7 +122,7 @@ class Context:
         p = ws["planes"]
         s = capi.ModSceneFlowPlanes()
         for i, k in enumerate(PLANES):
-            setattr(s, k, p[i].data_ptr())
+            setattr(s, k, p[i].data_ptr() if (ws.get("xy", True) or k not in ("x", "y")) else None)
         s.dynamic_mask = ws["mask"].data_ptr() if with_mask else None
         s.cloud_aos = ws["aos"].data_ptr() if ws.get("aos") is not None else None
         s.depth = ws["depth"].data_ptr() if ws.get("depth") is not None else None

@@ -130,3 +130,89 @@ def test_other_window_sizes(oracle, n):
     ys, xs = np.mgrid[0:H, 0:W]
     d = ((xs % (2 * n + 3)) < 2) & ((ys % (n + 2)) < 1)              # dozens of two-pixel pieces per tile
     _check(oracle, _make_cloud(W, H, d, flat, rng), _prm(2, n), W, H)
+
+
+def test_image_narrower_than_the_window(oracle):
+    """W < neighbor_distance (allowed: max_width >= 1, n up to 10): the halo-column depth loads of tile column 0 stay inside the
+    image's rows (round 4 read up to n - 1 floats past the end of the plane's last row)."""
+    rng = np.random.default_rng(77)
+    for (W, H, n) in ((8, 8, 10), (3, 40, 7), (1, 30, 4), (9, 17, 10)):
+        _check(oracle, _make_cloud(W, H, rng.random((H, W)) < 0.7, np.full((H, W), 5.0), rng), _prm(2, n), W, H)
+
+
+def _fused(oracle, cam, prm, z, dyn, shift=6.0):
+    """One frame through the FUSED path (mod_process_dev: the scene-flow epilogue writes mask words + their depth ranges, k_ccl_bits
+    decides one-class tiles from the ranges) against the oracle.  A camera at rest, previous disparity = now, flow = `shift` px on the
+    pixels that are to be dynamic and 0 elsewhere: with dynamic_flow_diff = 1 exactly those (where the warp stays in the image) move."""
+    from moving_object_detector_amd.pipeline import Context, PLANES
+    from util import bits_equal, compare_objects
+    H, W = z.shape
+    fT = np.float32(cam.disp_f) * np.float32(cam.disp_T)
+    d = (fT / z.astype(np.float32)).astype(np.float32)
+    flow = np.zeros((H, W, 2), np.float32)
+    flow[..., 0] = np.where(dyn, np.float32(shift), np.float32(0.0))
+    t, q, dt = np.zeros(3), np.array([0.0, 0.0, 0.0, 1.0]), 0.1
+    ctx = Context(W, H, max_frames=1, max_objects=W * H // prm.cluster_size + 1)
+    ctx.set_camera(cam); ctx.set_params(prm)
+    ws = ctx.workspace(1)
+    dev = ctx.device
+    dn = torch.from_numpy(d[None]).to(dev)
+    b = ctx.make_batch(dn, dn.clone(), torch.from_numpy(flow[None]).to(dev), t[None], q[None], [dt])
+    for _ in range(2):                                               # the second call runs over the first one's ranges / headers
+        assert ctx.process(b, ws) == 0
+    ctx.synchronize()
+    ref = oracle.construct(cam, prm, d, d, flow, t, q, dt, "tidy")
+    planes = ws["planes"].cpu().numpy()
+    for i, k in enumerate(PLANES):
+        assert bits_equal(planes[i, 0], ref[k]), k
+    rl, ro, K = oracle.cluster(ref, prm, "tidy", max_objects=W * H)
+    assert int(ws["n_clusters"][0]) == K
+    assert np.array_equal(ws["labels"][0].cpu().numpy(), rl), int((ws["labels"][0].cpu().numpy() != rl).sum())
+    compare_objects(ctx.objects_to_host(ws)[0], ro, strict_velocity=True)
+    ctx.close()
+    return int((rl >= 0).sum())
+
+
+@pytest.mark.parametrize("W,H", [(330, 70), (640, 96), (257, 33), (1242, 40), (131, 50)])
+def test_fused_path_depth_ranges(oracle, W, H):
+    """The per-word depth ranges of the fused path (round 5) on layouts where they decide: one depth everywhere (every tile takes the
+    range path), two depths within depth_diff (still one class), a depth step INSIDE the left neighbour word but outside the halo
+    columns (the range test fails although the grid is one class: the row path must give the same answer), steps along word borders,
+    across rows, single far pixels inside a near word (the range must cover them), random levels, and widths served by each of the
+    three scene-flow kernels (multiple of 4, even, odd)."""
+    from moving_object_detector_amd import synth
+    cam = synth.make_camera(W, H)
+    prm = synth.Params(dynamic_flow_diff=1, cluster_size=3, neighbor_distance=4, depth_diff=0.15, dynamic_speed=0.05)
+    rng = np.random.default_rng(W + H)
+    xs = np.arange(W)[None, :] + np.zeros((H, 1), int)
+    ys = np.arange(H)[:, None] + np.zeros((1, W), int)
+    layouts = {
+        "flat": np.full((H, W), 5.0),
+        "two_near": 5.0 + 0.1 * ((xs // 9 + ys // 5) % 2),
+        "step_in_left_word": np.where(xs % 64 < 40, 5.0, 6.0) + 0.0 * ys,      # the step sits 24 columns left of every tile
+        "step_at_word_border": np.where((xs // 64) % 2 == 0, 5.0, 6.0) + 0.0 * ys,
+        "step_at_halo": np.where((xs + 3) % 64 < 32, 5.0, 6.0) + 0.0 * ys,      # inside the 4 halo columns
+        "rows": np.where((ys // 7) % 2 == 0, 5.0, 5.5) + 0.0 * xs,
+        "levels": 5.0 + 0.4 * rng.integers(0, 3, size=(H, W)),
+    }
+    far = np.full((H, W), 5.0)
+    far[rng.random((H, W)) < 0.004] = 9.0                                       # lone far pixels inside near words
+    layouts["lone_far_pixels"] = far
+    total = 0
+    for name, z in layouts.items():
+        for density in (0.35, 1.0):
+            dyn = rng.random((H, W)) < density
+            total += _fused(oracle, cam, prm, z, dyn)
+    assert total > 0                                                            # the layouts do produce clusters
+
+
+def test_fused_path_other_window_sizes(oracle):
+    from moving_object_detector_amd import synth
+    W, H = 200, 60
+    cam = synth.make_camera(W, H)
+    rng = np.random.default_rng(5)
+    xs = np.arange(W)[None, :] + np.zeros((H, 1), int)
+    for n in (1, 2, 7, 10, 12):                                                 # 12: outside the bit kernel's range (union-find kernel, no ranges read)
+        prm = synth.Params(dynamic_flow_diff=1, cluster_size=2, neighbor_distance=n, depth_diff=0.15, dynamic_speed=0.05)
+        for z in (np.full((H, W), 4.0), np.where(xs % 64 < 50, 4.0, 4.6) + 0.0):
+            _fused(oracle, cam, prm, z, rng.random((H, W)) < 0.5)

@@ -82,6 +82,16 @@ def test_host_entry_points_match_golden(path):
     assert rc == 0 and n3.value == n.value and objs3[: n3.value].tobytes() == objs[: n.value].tobytes()
     rc = ctx.lib.mod_cluster_cloud_host(ctx.h, cloud.ctypes.data, W, H, 32, 32 * W, None, objs3.ctypes.data, 64, C.byref(n3))
     assert rc == 0 and n3.value == n.value and objs3[: n3.value].tobytes() == objs[: n.value].tobytes()
+    # a caller that only counts the objects (n_objects alone) still gets the real count: the cluster stage runs
+    n5 = C.c_int32(-1)
+    rc = ctx.lib.mod_process_frame_host(ctx.h, g["d_now"].ctypes.data, g["d_prev"].ctypes.data, g["flow"].ctypes.data, tf,
+                                        float(np.asarray(g["dt"]).item()), None, None, None, 0, C.byref(n5))
+    assert rc == 0 and n5.value == n.value
+    # ... and with no cluster output at all (not even the count) only the scene-flow stage runs: the cloud is the same
+    cloud5 = np.zeros((H, W, 8), np.float32)
+    rc = ctx.lib.mod_process_frame_host(ctx.h, g["d_now"].ctypes.data, g["d_prev"].ctypes.data, g["flow"].ctypes.data, tf,
+                                        float(np.asarray(g["dt"]).item()), cloud5.ctypes.data, None, None, 0, None)
+    assert rc == 0 and cloud5.tobytes() == cloud.tobytes()
     # a clusterer-only context (the nodelet in its own process): no camera is ever set, the size comes with the cloud
     from moving_object_detector_amd.pipeline import Context
     solo = Context(W + 7, H + 3, max_frames=1, max_objects=(W + 7) * (H + 3) // prm.cluster_size + 1)

@@ -279,3 +279,50 @@ def test_disparity_copy_survives_guard_skipped_frames_that_wrap_the_ring():
     ctx.synchronize()
     ctx.close()
     assert np.array_equal(disp, g["disparity"])
+
+
+def test_parameters_may_change_between_submits(oracle):
+    """include/mod_sf.h: the PARAMETERS may be reconfigured while frames are in flight — the reference's reconfigureCB runs between two
+    stereoCallbacks (scene_flow_constructor.cpp:401-407, clusterer_nodelet.cpp:345-352), i.e. after frame t was handed to
+    construct_thread_ and before it is joined — and every kernel takes them by value at submit time: a frame in flight completes with
+    the parameters of ITS submit, the next submit uses the new ones.  The second change raises neighbor_distance, which re-allocates
+    the link-request scratch (mod_set_params synchronises the stream for that)."""
+    from moving_object_detector_amd import capi, synth
+    from moving_object_detector_amd.pipeline import Context, OBJECT_DTYPE
+    from util import compare_objects
+    W, H, F, CAP = 320, 240, 4, 64
+    cam, b = _sequence(W, H, F, seed=33)
+    prms = [synth.Params(dynamic_flow_diff=1, cluster_size=100, neighbor_distance=2),
+            synth.Params(dynamic_flow_diff=1, cluster_size=400, neighbor_distance=2, depth_diff=0.05),
+            synth.Params(dynamic_flow_diff=2, cluster_size=100, neighbor_distance=9, dynamic_speed=0.2),
+            synth.Params(dynamic_flow_diff=1, cluster_size=150, neighbor_distance=4)]
+    tfs = capi.transforms_array(b["t"], b["q"])
+    ctx = Context(W, H, max_frames=1)
+    ctx.set_camera(cam)
+    labels = np.full((F, H, W), -7, np.int32)
+    objs = [np.zeros(CAP, OBJECT_DTYPE) for _ in range(F)]
+    t, n = C.c_int32(-1), C.c_int32(-1)
+    tickets, counts = [], []
+    for f in range(F):
+        ctx.set_params(prms[f])                              # between two submits, frames f-1, f-2 still in flight
+        if len(tickets) == capi.MOD_PIPELINE_DEPTH:
+            assert ctx.lib.mod_collect_frame_host(ctx.h, tickets.pop(0), C.byref(n)) == 0
+            counts.append(n.value)
+        rc = ctx.lib.mod_submit_frame_host(ctx.h, b["disparity_now"][f].ctypes.data, b["disparity_prev"][f].ctypes.data, b["flow"][f].ctypes.data,
+                                           C.byref(tfs[f]), float(b["dt"][f]), None, labels[f].ctypes.data, objs[f].ctypes.data, CAP, C.byref(t))
+        assert rc == 0, ctx.lib.mod_last_error(ctx.h)
+        tickets.append(t.value)
+    ctx.set_params(synth.Params(cluster_size=5000))          # after the last submit, before its collect: must not reach back
+    while tickets:
+        assert ctx.lib.mod_collect_frame_host(ctx.h, tickets.pop(0), C.byref(n)) == 0
+        counts.append(n.value)
+    ctx.close()
+    total = 0
+    for f in range(F):
+        ref = oracle.construct(cam, prms[f], b["disparity_now"][f], b["disparity_prev"][f], b["flow"][f], b["t"][f], b["q"][f], float(b["dt"][f]), "tidy")
+        rl, ro, _ = oracle.cluster(ref, prms[f], "tidy", max_objects=W * H)
+        assert np.array_equal(labels[f], rl), f
+        assert counts[f] == len(ro), (f, counts[f], len(ro))
+        compare_objects(objs[f][: counts[f]], ro, strict_velocity=True)
+        total += len(ro)
+    assert total > 0

@@ -16,11 +16,10 @@ lib.mod_debug_read.argtypes=[C.c_void_p,C.c_int,C.c_void_p,C.c_uint64]
 N=W*H
 mb=np.zeros(N,np.uint32); lib.mod_debug_read(ctx.h,0,mb.ctypes.data,mb.nbytes); mp=np.zeros(N,np.uint32); lib.mod_debug_read(ctx.h,4,mp.ctypes.data,mp.nbytes); mem=np.stack([mb,mp],1)
 cl=np.zeros((16,8),np.int32); lib.mod_debug_read(ctx.h,1,cl.ctypes.data,cl.nbytes)
-cur=np.zeros(16,np.int32); lib.mod_debug_read(ctx.h,3,cur.ctypes.data,cur.nbytes)
 labels=ws["labels"][0].cpu().numpy()
 vx,vy,vz=[ws["planes"][i,0].cpu().numpy() for i in (3,4,5)]
 K=int(ws["n_clusters"][0])
-print("K",K,"cursors",cur[:K])
+print("K",K)
 for k in range(K):
     comp,size,off,medpix,medbits,amb=cl[k][:6]
     seg=mem[off:off+size]
