@@ -1331,11 +1331,14 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
         py[j] = (float)(c.rayy[min(y0 + r0 + j, c.H - 1)] * zd);
       }
     }
+    uint32_t nb[RPW];                                // ||v|| bit patterns (norms are >= 0 and never NaN: the patterns order like the values)
+#pragma unroll
+    for (int j = 0; j < RPW; j++) nb[j] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
 #pragma unroll
     for (int j = 0; j < RPW; j++) {
       if (nl[j] >= 0) {
         if (MOD_CHECK(a, slot[j] >= 0 && (size_t)slot[j] < N, 8)) {
-          a.mbits[fN + slot[j]] = __float_as_uint(norm3_f32(vx[j], vy[j], vz[j]));
+          a.mbits[fN + slot[j]] = nb[j];
           a.mpix[fN + slot[j]] = (uint32_t)((y0 + r0 + j) * c.W + x);
         }
       }
@@ -1352,52 +1355,80 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
       const uint64_t b = __ballot(mine >= 0);
       if (b == 0) break;                               // wave-uniform
       const int L = __builtin_amdgcn_readlane(mine, __ffsll((unsigned long long)b) - 1);
-      uint32_t mn0 = 0xffffffffu, mn1 = 0xffffffffu, mn2 = 0xffffffffu, mx0 = 0u, mx1 = 0u, mx2 = 0u;
+      uint32_t mn0 = 0xffffffffu, mn1 = 0xffffffffu, mn2 = 0xffffffffu, mx0 = 0u, mx1 = 0u, mx2 = 0u, mn3 = 0xffffffffu, mx3 = 0u;
 #pragma unroll
       for (int j = 0; j < RPW; j++) {
         if (pend[j] == L) {
           const uint32_t ox = f2ord(px[j]), oy = f2ord(py[j]), oz = f2ord(pz[j]);
           mn0 = min(mn0, ox); mx0 = max(mx0, ox); mn1 = min(mn1, oy); mx1 = max(mx1, oy); mn2 = min(mn2, oz); mx2 = max(mx2, oz);
+          mn3 = min(mn3, nb[j]); mx3 = max(mx3, nb[j]);
           pend[j] = -1;
         }
       }
-      mn0 = wave_min_u32(mn0); mn1 = wave_min_u32(mn1); mn2 = wave_min_u32(mn2);
-      mx0 = wave_max_u32(mx0); mx1 = wave_max_u32(mx1); mx2 = wave_max_u32(mx2);
-      // ONE atomic instruction per (wave, cluster): lanes 0..5 each fold one word (an atomic instruction costs the CU's memory
-      // pipeline the same whether one lane or six are active); the maxima are kept complemented so that all six are minima
-      uint32_t v = ~mx2;
+      mn0 = wave_min_u32(mn0); mn1 = wave_min_u32(mn1); mn2 = wave_min_u32(mn2); mn3 = wave_min_u32(mn3);
+      mx0 = wave_max_u32(mx0); mx1 = wave_max_u32(mx1); mx2 = wave_max_u32(mx2); mx3 = wave_max_u32(mx3);
+      // ONE atomic instruction per (wave, cluster): lanes 0..7 each fold one word (an atomic instruction costs the CU's memory
+      // pipeline the same whether one lane or eight are active); the maxima are kept complemented so that all eight are minima.
+      // Words 6, 7 (round 5): smallest / largest ||v|| of the members — k_median starts its selection from that range instead of
+      // scanning the members for it
+      uint32_t v = ~mx3;
       v = lane == 0 ? mn0 : v; v = lane == 1 ? mn1 : v; v = lane == 2 ? mn2 : v; v = lane == 3 ? ~mx0 : v; v = lane == 4 ? ~mx1 : v;
-      if (lane < 6) atomicMin(&a.cbox[(size_t)f * a.max_objects + L].w[lane], v);
+      v = lane == 5 ? ~mx2 : v; v = lane == 6 ? mn3 : v;
+      if (lane < 8) atomicMin(&a.cbox[(size_t)f * a.max_objects + L].w[lane], v);
     }
   }
 }
 
 // Median-velocity member per cluster: the element at position size/2 of the members sorted by ||v|| descending
-// (clusterer_nodelet.cpp:168-174).  All norms are finite and >= 0, so their F32 bit patterns order like the values:
+// (clusterer_nodelet.cpp:168-174).  All norms are >= 0 and never NaN, so their F32 bit patterns order like the values:
 // a range-adaptive 2048-bin histogram over (bits - min) >> shift isolates the bin that holds rank size/2, its members
-// (a handful) are ranked exactly in LDS; degenerate distributions narrow the range and repeat.
-// The member norms are read from HBM ONCE, into registers (kMedRegs per thread, 32 Ki members per workgroup; the tail of
-// a larger cluster is re-read per pass): every narrowing round then runs out of registers and LDS, so a cluster costs a
-// few HBM round trips instead of one per pass.  Neighbouring members have similar norms, i.e. a wave's lanes mostly hit
-// the same histogram bin; the LDS unit serialises those adds itself.
-constexpr int kMedThreads = 1024, kMedBins = 2048, kMedRegs = 32;
+// (up to kMedDirect of them) are ranked exactly in LDS; degenerate distributions narrow the range and repeat.
+// Round 5 — a cluster is a chain of barriers and memory round trips, so what counts is how many clusters are in flight; rounds 1-4
+// held the norms in registers (32 per thread: 125 VGPRs with spills, ONE workgroup per CU, 25 us per cluster).  Now:
+//   * the norms are STREAMED from L2 in every pass (eight loads in flight per thread; a cluster is some 90 KB that its own workgroup
+//     read a few microseconds before): under 32 VGPRs, two 1024-thread workgroups per CU;
+//   * the members' norm range comes with the cluster's box record (k_final folds it with the same atomic instruction): no pass
+//     over the members for it;
+//   * the bin that holds the rank is found by all 16 waves (two bins per thread, one wave scan + 16 wave totals), not by wave 0
+//     walking 2048 bins; the bins are zeroed again as they are read;
+//   * a bin with up to kMedDirect members ends the rounds: they are compacted with their list positions, ranked directly, and the
+//     tie-break (smallest column-major index, differing vectors flagged) runs on that list — two passes over the norms for most
+//     clusters;
+//   * the rare paths left the kernel: NaN coordinates of a caller's cloud are k_box_nan's, the tie replay k_median_ties'.
+constexpr int kMedThreads = 1024, kMedBins = 2048, kMedDirect = 256, kMedCand = kMedBins / 2;
 
-// hist[bin] += 1 for every lane with `on`.  (Aggregating the lanes of a bin with ballots first was measured: slower than the
-// LDS unit's own handling of same-address atomics.)
-__device__ __forceinline__ void hist_add(uint32_t *hist, bool on, uint32_t bin, int) {
-  if (on) atomicAdd(&hist[bin], 1u);
+// box of a cluster record -> bounding_box / center of the object (cluster2MovingObject, clusterer_nodelet.cpp:151-161): F32 max - min
+// and (min + max) / 2, widened to F64 (getMinMax3D starts from +-FLT_MAX: members at +inf leave the minimum there, members at -inf the maximum)
+__device__ __forceinline__ void box_to_object(const ClusterBox &rec, ModObject *o) {
+  for (int d = 0; d < 3; d++) {
+    const float mn = fminf(ord2f(rec.w[d]), 3.402823466e38f), mx = fmaxf(ord2f(~rec.w[3 + d]), -3.402823466e38f);
+    o->bounding_box[d] = (double)(mx - mn);
+    o->center[d] = (double)((mn + mx) / 2.0f);
+  }
 }
 
-__global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
+// f(bits, list position) for every member: kMedFlight coalesced loads in flight per thread — unconditional, at clamped positions
+// (a predicated load is an exec-masked region of its own: the loads would leave one by one), 0xffffffff (not a norm) past the end
+constexpr int kMedFlight = 10;   // (12: the first spills at 64 VGPRs)
+template <class F> __device__ __forceinline__ void med_stream(const uint32_t *sbits, int size, int tid, F f) {
+  for (int i0 = tid; i0 < size; i0 += kMedThreads * kMedFlight) {
+    uint32_t b[kMedFlight];
+#pragma unroll
+    for (int u = 0; u < kMedFlight; u++) b[u] = *(const uint32_t *)((const char *)sbits + 4u * (uint32_t)min(i0 + u * kMedThreads, size - 1));
+#pragma unroll
+    for (int u = 0; u < kMedFlight; u++) { const int i = i0 + u * kMedThreads; f(i < size ? b[u] : 0xffffffffu, i); }
+  }
+}
+
+__global__ __launch_bounds__(kMedThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_median(DevCam c, ClArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t N = (size_t)c.W * c.H;
   const int nwork = a.counters[6];
-  __shared__ uint32_t hist[kMedBins];
-  __shared__ uint32_t s_red[2][16];
-  __shared__ uint32_t s_lo, s_hi, s_bin, s_rem, s_cnt, s_val, s_ties;
+  __shared__ uint32_t hist[kMedBins];                // the bins; between the rounds and the tie-break: candidates (bits | list position)
+  __shared__ uint32_t s_wsum[kMedThreads / 64];
+  __shared__ uint32_t s_bin, s_rem, s_inbin, s_cnt, s_val, s_ties;
   __shared__ unsigned long long s_best;
-  __shared__ int s_amb;
-  constexpr uint32_t kNone = 0xffffffffu;            // not a norm (norms are finite: bits <= 0x7f7fffff)
+  __shared__ int s_amb, s_item;
 #ifdef MOD_PHASE_COUNTERS
   const unsigned long long bt0 = wall_clock64();
   if (tid == 0) atomicMin(&a.dbg[42], bt0);
@@ -1405,201 +1436,174 @@ __global__ __launch_bounds__(kMedThreads) void k_median(DevCam c, ClArgs a) {
     __device__ ~BlockEnd() { const unsigned long long t1 = wall_clock64(); if (tid == 0) { atomicMax(&d[43], t1); if (busy) { atomicAdd(&d[40], t1 - t0); atomicAdd(&d[41], 1ull); } } } };
   BlockEnd be{a.dbg, bt0, tid, (int)blockIdx.x < nwork};
 #endif
-  __shared__ int s_item;
+  hist[tid] = 0u; hist[tid + kMedThreads] = 0u;      // every phase leaves the bins zeroed again
   for (;;) {
     // clusters differ 10x in size: workgroups take the next one when they are free (counters[5]) instead of a fixed share
-    if (tid == 0) s_item = atomicAdd(&a.counters[5], 1);
+    if (tid == 0) { s_item = atomicAdd(&a.counters[5], 1); s_cnt = 0u; s_best = ~0ull; s_amb = 0; }
     __syncthreads();
-    const int wi = s_item;
+    // (the work item is the same in every lane, but arrives through LDS in a vector register: as a scalar, everything derived from
+    // it — frame, cluster record, the list's base addresses — stays on the scalar unit and the member loads are `base + lane offset`)
+    const int wi = __builtin_amdgcn_readfirstlane(s_item);
     if (wi >= nwork) break;                          // block-uniform; every workgroup gets here
     const uint32_t item = a.worklist[wi];
     const int f = (int)(item / (uint32_t)a.max_objects), k = (int)(item % (uint32_t)a.max_objects);
     ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
-    const int size = MOD_CHECK(a, ci->size >= 1 && ci->offset >= 0 && (size_t)ci->offset + (size_t)ci->size <= N, 9) ? ci->size : 0;
+    const int ci_size = __builtin_amdgcn_readfirstlane(ci->size), ci_off = __builtin_amdgcn_readfirstlane(ci->offset);
+    const int size = MOD_CHECK(a, ci_size >= 1 && ci_off >= 0 && (size_t)ci_off + (size_t)ci_size <= N, 9) ? ci_size : 0;
     if (size == 0) continue;                                        // (checked build only; block-uniform)
-    const uint32_t *sbits = a.mbits + (size_t)f * N + ci->offset;   // ||v|| bits of the members ...
-    const uint32_t *spix = a.mpix + (size_t)f * N + ci->offset;     // ... and their pixel indices
-    const ClusterBox rec = a.cbox[(size_t)f * a.max_objects + k];   // complete: k_final has finished; in flight meanwhile
+    const uint32_t *sbits = a.mbits + (size_t)f * N + ci_off;       // ||v|| bits of the members ...
+    const uint32_t *spix = a.mpix + (size_t)f * N + ci_off;         // ... and their pixel indices
+    const ClusterBox *box = a.cbox + (size_t)f * a.max_objects + k; // complete: k_final has finished
 #ifdef MOD_PHASE_COUNTERS
     unsigned long long mt0 = wall_clock64(), mt1;
 #define MSTAMP(i) { __syncthreads(); mt1 = wall_clock64(); if (tid == 0) atomicAdd(&a.dbg[i], mt1 - mt0); mt0 = mt1; }
 #else
 #define MSTAMP(i)
 #endif
-    // ---- the members' norms: registers (member u * T + tid in v[u]) + HBM tail ----
-    uint32_t v[kMedRegs];
-#pragma unroll
-    for (int u = 0; u < kMedRegs; u++) { const int i = u * kMedThreads + tid; v[u] = i < size ? sbits[i] : kNone; }
-    const int tail0 = kMedRegs * kMedThreads;
-    // ---- value range ----
-    uint32_t mn = kNone, mx = 0u;
-#pragma unroll
-    for (int u = 0; u < kMedRegs; u++) { mn = v[u] < mn ? v[u] : mn; mx = (v[u] != kNone && v[u] > mx) ? v[u] : mx; }
-    for (int i = tail0 + tid; i < size; i += kMedThreads) { const uint32_t b = sbits[i]; mn = b < mn ? b : mn; mx = b > mx ? b : mx; }
-    mn = wave_min_u32(mn); mx = wave_max_u32(mx);
-    if (lane == 0) { s_red[0][wv] = mn; s_red[1][wv] = mx; }
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t l0 = kNone, h0 = 0u;
-      for (int i = 0; i < kMedThreads / 64; i++) { l0 = s_red[0][i] < l0 ? s_red[0][i] : l0; h0 = s_red[1][i] > h0 ? s_red[1][i] : h0; }
-      s_lo = l0; s_hi = h0;
-    }
-    __syncthreads();
-    uint32_t lo = s_lo, hi = s_hi, rem = (uint32_t)(size / 2);
+    uint32_t lo = box->w[6], hi = ~box->w[7], rem = (uint32_t)(size / 2);   // the members' norm range (k_final)
+    if (!MOD_CHECK(a, lo <= hi, 9)) { lo = 0u; hi = 0x7f800000u; }
     bool exact = false;                      // the live range is a single value: every member of it ties
     uint32_t val = 0, nties = 0;
     MSTAMP(26)
-    for (int round = 0; round < 8; round++) {        // <= 3 narrowing rounds in practice; the bound only guards against corrupt input
+    for (int round = 0; round < 8; round++) {        // one or two rounds in practice; the bound only guards against corrupt input
       const uint32_t range = hi - lo;
       const int shift = range < (uint32_t)kMedBins ? 0 : (32 - __clz((int)range) - 11);   // (range >> shift) < 2048
-      // ---- histogram of the live range ----
-      for (int i = tid; i < kMedBins; i += kMedThreads) hist[i] = 0;
+      // ---- histogram of the live range (the bins are zero: start of the kernel / the scan of the round before) ----
+      med_stream(sbits, size, tid, [&](uint32_t b, int) { if (b >= lo && b <= hi) atomicAdd(&hist[(b - lo) >> shift], 1u); });
       __syncthreads();
-#pragma unroll
-      for (int u = 0; u < kMedRegs; u++) {
-        if (u * kMedThreads >= size) break;            // block-uniform
-        hist_add(hist, v[u] >= lo && v[u] <= hi, (v[u] - lo) >> shift, lane);
-      }
-      for (int i0 = tail0; i0 < size; i0 += kMedThreads) {
-        const int i = i0 + tid;
-        const uint32_t b = i < size ? sbits[i] : kNone;
-        hist_add(hist, b >= lo && b <= hi, (b - lo) >> shift, lane);
-      }
+      MSTAMP(30 + (round > 0 ? 2 : 0))
+      // ---- bin that holds descending rank `rem`: thread t owns bins 2047 - 2t and 2046 - 2t (walking down from the top) ----
+      const int b0 = kMedBins - 1 - 2 * tid;
+      const uint32_t h0 = hist[b0], h1 = hist[b0 - 1];
+      hist[b0] = 0u; hist[b0 - 1] = 0u;
+      uint32_t incl = h0 + h1;                       // inclusive prefix over the wave's lanes
+      for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      if (lane == 63) s_wsum[wv] = incl;
       __syncthreads();
-      // ---- bin that holds descending rank `rem`: wave 0, lane l owns bins [2047-32l-31, 2047-32l] ----
-      if (wv == 0) {
-        uint32_t sum = 0;
-        const int top = kMedBins - 1 - 32 * lane;
-        for (int j = 0; j < 32; j++) sum += hist[top - j];
-        uint32_t incl = sum;                                      // inclusive prefix over lanes (= bins from the top)
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        const uint32_t excl = incl - sum;
-        if (rem >= excl && rem < incl) {
-          uint32_t r = rem - excl;
-          int bin = top;
-          for (int j = 0; j < 32; j++, bin--) { const uint32_t h = hist[bin]; if (r < h) break; r -= h; }
-          s_bin = (uint32_t)bin; s_rem = r;
-        }
+      uint32_t before = 0;                           // members in the waves above this one
+      for (int w2 = 0; w2 < kMedThreads / 64; w2++) before += (w2 < wv) ? s_wsum[w2] : 0u;
+      const uint32_t upto = before + incl, excl = upto - (h0 + h1);
+      if (rem >= excl && rem < upto) {               // exactly one thread
+        const bool first = rem - excl < h0;
+        s_bin = (uint32_t)(first ? b0 : b0 - 1); s_rem = first ? rem - excl : rem - excl - h0; s_inbin = first ? h0 : h1;
       }
       __syncthreads();
-      const uint32_t bin = s_bin, inbin = hist[bin];
+      const uint32_t bin = s_bin, inbin = s_inbin;
       rem = s_rem;
       const uint32_t nlo = lo + (bin << shift);
       const uint32_t nhi = shift ? (nlo + ((1u << shift) - 1u)) : nlo;
       lo = nlo; hi = nhi < hi ? nhi : hi;
+      MSTAMP(31 + (round > 0 ? 2 : 0))
       if (shift == 0) { exact = true; val = lo; nties = inbin; break; }
-      if (inbin <= 64u) break;                                      // rank the few survivors directly
-      __syncthreads();                                              // hist is rewritten by the next round
+      if (inbin <= (uint32_t)kMedDirect) break;                     // rank the survivors directly
     }
     MSTAMP(27)
+    const float *pvx = a.vx + (size_t)f * N, *pvy = a.vy + (size_t)f * N, *pvz = a.vz + (size_t)f * N;
+    uint32_t best, bvx, bvy, bvz;
+    // canonical pick among the members of norm `val`: the smallest column-major index (the member list is in tile order)
+    auto offer = [&](uint32_t p) {
+      const uint32_t px = p % (uint32_t)c.W, py = p / (uint32_t)c.W;
+      atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | p);
+    };
+    auto settle = [&]() {                            // after a barrier: the pick and its vector
+      best = (uint32_t)(s_best & 0xffffffffull);
+      if (s_best == ~0ull) best = spix[0];           // unreachable for consistent input; keeps every access in bounds
+      if (!MOD_CHECK(a, s_best != ~0ull && (size_t)best < N, 10)) best = 0;
+      bvx = __float_as_uint(pvx[best]); bvy = __float_as_uint(pvy[best]); bvz = __float_as_uint(pvz[best]);
+    };
+    auto differs = [&](uint32_t p) {
+      return p != best && (__float_as_uint(pvx[p]) != bvx || __float_as_uint(pvy[p]) != bvy || __float_as_uint(pvz[p]) != bvz);
+    };
     if (!exact) {
-      // ---- exact rank among the (<= 64) members left in [lo, hi]: compact them (hist is free now), then count ----
+      // ---- the (<= kMedDirect) members left in [lo, hi], compacted with their list positions into the (zeroed) bins: exact rank,
+      // then the tie-break on the same list ----
+      med_stream(sbits, size, tid, [&](uint32_t b, int i) {
+        if (b >= lo && b <= hi) { const uint32_t s0 = atomicAdd(&s_cnt, 1u); if (s0 < (uint32_t)kMedCand) { hist[s0] = b; hist[kMedCand + s0] = (uint32_t)i; } }
+      });
       __syncthreads();
-      if (tid == 0) s_cnt = 0;
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < kMedRegs; u++) if (v[u] >= lo && v[u] <= hi) { const uint32_t s0 = atomicAdd(&s_cnt, 1u); if (s0 < (uint32_t)kMedBins) hist[s0] = v[u]; }
-      for (int i = tail0 + tid; i < size; i += kMedThreads) {
-        const uint32_t b = sbits[i];
-        if (b >= lo && b <= hi) { const uint32_t s0 = atomicAdd(&s_cnt, 1u); if (s0 < (uint32_t)kMedBins) hist[s0] = b; }
-      }
-      __syncthreads();
-      const int fn = min((int)s_cnt, kMedBins);
+      MSTAMP(34)
+      const int fn = MOD_CHECK(a, s_cnt <= (uint32_t)kMedCand, 9) ? (int)s_cnt : kMedCand;
+      uint32_t mine = 0, mypix = 0;
       if (tid < fn) {
-        const uint32_t b = hist[tid];
+        mine = hist[tid];
         uint32_t gt = 0, ge = 0;
-        for (int j = 0; j < fn; j++) { const uint32_t o = hist[j]; gt += o > b; ge += o >= b; }
-        if (gt <= rem && rem < ge) { s_val = b; s_ties = ge - gt; }  // every member of that value writes the same
+        for (int j = 0; j < fn; j++) { const uint32_t o = hist[j]; gt += o > mine; ge += o >= mine; }
+        if (gt <= rem && rem < ge) { s_val = mine; s_ties = ge - gt; }  // every member of that value writes the same
       }
       __syncthreads();
       val = s_val; nties = s_ties;
+      const bool tied = tid < fn && mine == val;
+      if (tied) { mypix = spix[hist[kMedCand + tid]]; offer(mypix); }
+      __syncthreads();
+      if (tid < fn) { hist[tid] = 0u; hist[kMedCand + tid] = 0u; }   // the bins are a histogram again
+      settle();
+      if (nties > 1u && tied && differs(mypix)) s_amb = 1;
+    } else {
+      // ---- a single value fills the bin (quantised inputs: possibly thousands of members): the tie-break streams the list ----
+      med_stream(sbits, size, tid, [&](uint32_t b, int i) { if (b == val) offer(spix[i]); });
+      __syncthreads();
+      settle();
+      if (nties > 1u) med_stream(sbits, size, tid, [&](uint32_t b, int i) { if (b == val && differs(spix[i])) s_amb = 1; });
     }
+    __syncthreads();
     MSTAMP(28)
-    // ---- ties: canonical pick = smallest column-major index; flag ties between different vectors ----
-    if (tid == 0) { s_best = ~0ull; s_amb = 0; }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kMedRegs; u++) {
-      if (v[u] == val) {
-        const uint32_t p = spix[u * kMedThreads + tid];
-        const uint32_t px = p % (uint32_t)c.W, py = p / (uint32_t)c.W;
-        atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | p);
-      }
-    }
-    for (int i = tail0 + tid; i < size; i += kMedThreads) {
-      if (sbits[i] == val) {
-        const uint32_t p = spix[i];
-        const uint32_t px = p % (uint32_t)c.W, py = p / (uint32_t)c.W;
-        atomicMin(&s_best, ((unsigned long long)(px * (uint32_t)c.H + py) << 32) | p);
-      }
-    }
-    __syncthreads();
-    uint32_t best = (uint32_t)(s_best & 0xffffffffull);
-    if (s_best == ~0ull) best = spix[0];            // unreachable for consistent input; keeps every access in bounds
-    if (!MOD_CHECK(a, s_best != ~0ull && (size_t)best < N, 10)) best = 0;
-    const float bvx = a.vx[(size_t)f * N + best], bvy = a.vy[(size_t)f * N + best], bvz = a.vz[(size_t)f * N + best];
-    if (nties > 1u) {                                // block-uniform: a single member of that norm cannot tie
-      auto differs = [&](uint32_t p) {
-        const size_t q = (size_t)f * N + p;
-        return __float_as_uint(a.vx[q]) != __float_as_uint(bvx) || __float_as_uint(a.vy[q]) != __float_as_uint(bvy) ||
-               __float_as_uint(a.vz[q]) != __float_as_uint(bvz);
-      };
-#pragma unroll
-      for (int u = 0; u < kMedRegs; u++)
-        if (v[u] == val) { const uint32_t p = spix[u * kMedThreads + tid]; if (p != best && differs(p)) s_amb = 1; }
-      for (int i = tail0 + tid; i < size; i += kMedThreads)
-        if (sbits[i] == val) { const uint32_t p = spix[i]; if (p != best && differs(p)) s_amb = 1; }
-    }
-    __syncthreads();
     MSTAMP(29)
     if (tid == 0) {
       ci->med_pix = (int)best; ci->med_bits = val; ci->ambiguous = s_amb;
       if (s_amb) a.tielist[atomicAdd(&a.counters[7], 1)] = item;
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
-      o->velocity[0] = (double)bvx; o->velocity[1] = (double)bvy; o->velocity[2] = (double)bvz;
-      // bbox / centre (cluster2MovingObject, clusterer_nodelet.cpp:151-161): F32 max-min and (min+max)/2, widened to F64
-      // (getMinMax3D starts from +-FLT_MAX: members at +inf leave the minimum there, members at -inf the maximum)
-      for (int d = 0; d < 3; d++) {
-        const float mn = fminf(ord2f(rec.w[d]), 3.402823466e38f), mx = fmaxf(ord2f(~rec.w[3 + d]), -3.402823466e38f);
+      o->velocity[0] = (double)__uint_as_float(bvx); o->velocity[1] = (double)__uint_as_float(bvy); o->velocity[2] = (double)__uint_as_float(bvz);
+      box_to_object(*box, o);
+    }
+    // (the next turn's first barrier orders tid 0's reads of s_amb / s_best with their re-initialisation)
+    __syncthreads();
+  }
+}
+
+// NaN coordinates among a cluster's members — only possible for caller-supplied clouds (mod_cluster_dev / mod_cluster_cloud_host: the
+// scene-flow stage never marks a pixel dynamic without finite x, y, z), so the launcher starts this kernel for those calls only.
+// pcl::getMinMax3D's dense path folds min_p = min_p.min(pt) in member order (column-major) with SSE semantics "(a < b) ? a : b": a NaN
+// replaces the running value and the next point replaces the NaN, i.e. the result is the min / max over the members AFTER the
+// last NaN, or NaN when the last member is NaN.  One workgroup walks the launch's clusters; those without a NaN cost three loads.
+__global__ __launch_bounds__(kMedThreads) void k_box_nan(DevCam c, ClArgs a) {
+  const int tid = threadIdx.x;
+  const size_t N = (size_t)c.W * c.H;
+  const int nwork = a.counters[6];
+  __shared__ uint32_t s_last, s_mn, s_mx, s_n;
+  for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint32_t item = a.worklist[wi];
+    const int f = (int)(item / (uint32_t)a.max_objects), k = (int)(item % (uint32_t)a.max_objects);
+    const ClusterInfo *ci = a.clusters + (size_t)f * a.max_objects + k;
+    const ClusterBox rec = a.cbox[(size_t)f * a.max_objects + k];
+    bool anynan = false;
+    for (int d = 0; d < 3; d++) anynan = anynan || isnan(ord2f(rec.w[d])) || isnan(ord2f(~rec.w[3 + d]));
+    if (!anynan) continue;                           // block-uniform
+    const int size = ci->size;
+    const uint32_t *spix = a.mpix + (size_t)f * N + ci->offset;
+    const float *pl[3] = {a.x + (size_t)f * N, a.y + (size_t)f * N, a.z + (size_t)f * N};
+    for (int d = 0; d < 3; d++) {
+      __syncthreads();
+      if (tid == 0) { s_last = 0u; s_mn = 0xffffffffu; s_mx = 0u; s_n = 0u; }   // last NaN key + 1, min, max, survivors
+      __syncthreads();
+      for (int i = tid; i < size; i += kMedThreads) {
+        const uint32_t p = spix[i];
+        if (isnan(pl[d][p])) atomicMax(&s_last, (p % (uint32_t)c.W) * (uint32_t)c.H + p / (uint32_t)c.W + 1u);
+      }
+      __syncthreads();
+      const uint32_t lastnan = s_last;              // column-major key + 1 of the last NaN member, 0 if none
+      for (int i = tid; i < size; i += kMedThreads) {
+        const uint32_t p = spix[i];
+        const uint32_t key1 = (p % (uint32_t)c.W) * (uint32_t)c.H + p / (uint32_t)c.W + 1u;
+        if (key1 > lastnan) { const uint32_t o = f2ord(pl[d][p]); atomicMin(&s_mn, o); atomicMax(&s_mx, o); atomicAdd(&s_n, 1u); }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
+        const float nanv = __uint_as_float(0x7fc00000u);
+        float mn = s_n ? ord2f(s_mn) : nanv, mx = s_n ? ord2f(s_mx) : nanv;
+        if (lastnan == 0u) { mn = fminf(mn, 3.402823466e38f); mx = fmaxf(mx, -3.402823466e38f); }   // no NaN in this coordinate: the +-FLT_MAX start values hold
         o->bounding_box[d] = (double)(mx - mn);
         o->center[d] = (double)((mn + mx) / 2.0f);
-      }
-    }
-    __syncthreads();
-    // ---- NaN coordinates among the members (only possible for caller-supplied clouds: the scene-flow stage never marks a
-    // pixel dynamic without finite x,y,z).  pcl::getMinMax3D's dense path folds min_p = min_p.min(pt) in member order
-    // (column-major) with SSE semantics "(a < b) ? a : b": a NaN replaces the running value and the next point replaces
-    // the NaN, i.e. the result is the min / max over the members AFTER the last NaN, or NaN when the last member is NaN.
-    {
-      bool anynan = false;
-      for (int d = 0; d < 3; d++) anynan = anynan || isnan(ord2f(rec.w[d])) || isnan(ord2f(~rec.w[3 + d]));
-      if (anynan && a.x && a.y) {                    // block-uniform (a fused call without x, y planes cannot get here: its members' coordinates are finite)
-        const float *pl[3] = {a.x + (size_t)f * N, a.y + (size_t)f * N, a.z + (size_t)f * N};
-        for (int d = 0; d < 3; d++) {
-          if (tid == 0) { s_cnt = 0u; s_bin = 0xffffffffu; s_rem = 0u; s_val = 0u; }   // last NaN key+1, min, max, survivors
-          __syncthreads();
-          for (int i = tid; i < size; i += kMedThreads) {
-            const uint32_t p = spix[i];
-            if (isnan(pl[d][p])) atomicMax(&s_cnt, (p % (uint32_t)c.W) * (uint32_t)c.H + p / (uint32_t)c.W + 1u);
-          }
-          __syncthreads();
-          const uint32_t lastnan = s_cnt;             // column-major key + 1 of the last NaN member, 0 if none
-          for (int i = tid; i < size; i += kMedThreads) {
-            const uint32_t p = spix[i];
-            const uint32_t key1 = (p % (uint32_t)c.W) * (uint32_t)c.H + p / (uint32_t)c.W + 1u;
-            if (key1 > lastnan) { const uint32_t o = f2ord(pl[d][p]); atomicMin(&s_bin, o); atomicMax(&s_rem, o); atomicAdd(&s_val, 1u); }
-          }
-          __syncthreads();
-          if (tid == 0) {
-            ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
-            const float nanv = __uint_as_float(0x7fc00000u);
-            float mn = s_val ? ord2f(s_bin) : nanv, mx = s_val ? ord2f(s_rem) : nanv;
-            if (lastnan == 0u) { mn = fminf(mn, 3.402823466e38f); mx = fmaxf(mx, -3.402823466e38f); }   // no NaN in this coordinate: the +-FLT_MAX start values hold
-            o->bounding_box[d] = (double)(mx - mn);
-            o->center[d] = (double)((mn + mx) / 2.0f);
-          }
-          __syncthreads();
-        }
       }
     }
   }
@@ -1985,7 +1989,9 @@ void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // one 1024-thread workgroup fills a CU and costs ~80 ns of wave dispatch whether it finds work or not: launch at most one
   // per CU (fewer for small batches) and let each walk the launch's cluster list (k_select) / tie list (k_median)
-  hipLaunchKernelGGL(k_median, dim3(std::min(256, frames * 8)), dim3(kMedThreads), 0, s, c, a);
+  // (round 5: two 64-VGPR workgroups fit a CU — 512 of them)
+  hipLaunchKernelGGL(k_median, dim3(std::min(512, frames * 8)), dim3(kMedThreads), 0, s, c, a);
+  if (!a.xy_from_z) hipLaunchKernelGGL(k_box_nan, dim3(std::min(64, frames * 2)), dim3(kMedThreads), 0, s, c, a);   // a caller's cloud may hold NaN coordinates
   hipLaunchKernelGGL(k_median_ties, dim3(std::min(64, frames * 2)), dim3(kTieThreads), 0, s, c, a);
   hipLaunchKernelGGL(k_finalize, dim3((frames + 63) / 64), dim3(64), 0, s, c, a, frames);
 }

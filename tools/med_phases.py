@@ -27,5 +27,6 @@ print("clusters per frame %.2f; sizes: min %d median %d mean %d max %d; share > 
     len(sizes) / G, sizes.min(), np.median(sizes), sizes.mean(), sizes.max(), (sizes > 8192).mean(), (sizes > 16384).mean(), (sizes > 32768).mean()))
 n = max(int(out[41]), 1)
 print("k_median per cluster-carrying block (100 MHz ticks -> us), summed over blocks / busy blocks: load+range %.1f  rounds %.1f  exact rank %.1f  ties+flag %.1f" % tuple(out[i] / 100.0 / n for i in (26, 27, 28, 29)))
+print("  per busy block: round-0 pass %.1f scan %.1f | later rounds pass %.1f scan %.1f | compaction pass %.1f  (us)" % tuple(out[i] / 100.0 / n for i in (30, 31, 32, 33, 34)))
 print("k_median blocks: busy %d, mean busy-block life %.1f us, first start -> last end %.1f us" % (out[41], out[40] / n / 100.0, (out[43] - out[42]) / 100.0))
 print("k_median_ties (us, total over the launch): box %.1f  mask %.1f  place %.1f  (layout total %.1f)  hbm partition %.1f  lds %.1f" % tuple(out[i] / 100.0 for i in (20, 21, 22, 23, 24, 25)))
