@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-dist", action="store_true",
                     help="N = 1 only: skip the process group (by default a one-rank RCCL group is brought up so that the single-GPU "
                          "line drives the communicator, the device broadcast and the device all-reduce of the N-rank run)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the frame-at-a-time leg (steps of 1 / 8 / 64 pairs, outside `value`)")
     ap.add_argument("--no-config5", action="store_true", help="skip the short config-5 leg (on-GPU SGM disparity, outside `value`)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + config broadcast + stream sharding only, no GPU work (exercises the N-rank launch path on a CPU box)")
@@ -214,6 +215,61 @@ def config5_leg(dev, local_rank):
     return out, check
 
 
+def latency_leg(dev, local_rank, cam_s, prm_s, host, W, H, sizes=(1, 8, 64)):
+    """Frame-at-a-time figures, OUTSIDE `value`: the reference processes ONE pair per callback at 15 frames/s
+    (scene_flow_constructor.cpp:364-399, zed_common.yaml:24-25) and BASELINE's metric names ms/frame.  Device-resident inputs,
+    mod_process_dev on steps of 1 / 8 / 64 pairs: `ms` = a step's time with the steps enqueued back to back (what a node that
+    pipelines its frames sees), `ms_synchronous` = enqueue + wait, one step at a time (a node that needs frame t's objects before
+    it hands over frame t + 1), per-kernel times from a pass with all stage timers on."""
+    import numpy as np
+    import torch
+
+    from moving_object_detector_amd import capi
+    from moving_object_detector_amd.pipeline import Context
+
+    out = {"what": "mod_process_dev on device-resident steps of 1 / 8 / 64 pairs, six planes + labels + objects; ms = back-to-back steps, "
+                   "ms_synchronous = one step at a time with a wait after each"}
+    G = host["disparity_now"].shape[0]
+    for F in sizes:
+        idx = [i % G for i in range(F)]
+        ctx = Context(W, H, max_frames=F, device=local_rank)
+        ctx.set_camera(cam_s)
+        ctx.set_params(prm_s)
+        ws = ctx.workspace(F)
+        d_now = torch.from_numpy(np.ascontiguousarray(host["disparity_now"][idx])).to(dev)
+        d_prev = torch.from_numpy(np.ascontiguousarray(host["disparity_prev"][idx])).to(dev)
+        flow = torch.from_numpy(np.ascontiguousarray(host["flow"][idx])).to(dev)
+        batch = ctx.make_batch(d_now, d_prev, flow, host["t"][idx], host["q"][idx], host["dt"][idx])
+        steps = max(20, 400 // F)
+        for _ in range(10):
+            ctx.process(batch, ws)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.process(batch, ws)
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.process(batch, ws)
+            ctx.synchronize()
+        ms_sync = 1e3 * (time.perf_counter() - t0) / steps
+        ctx.set_profiling(True, stages=[i for i in range(capi.MOD_STAGE_COUNT) if i != capi.MOD_STAGE_CLUSTER_GROUP])
+        ctx.reset_stage_times()
+        for _ in range(20):
+            ctx.process(batch, ws)
+        torch.cuda.synchronize()
+        st = [ctx.stage_time(i) for i in range(capi.MOD_STAGE_COUNT)]
+        ctx.set_profiling(False)
+        out[f"pairs_{F}"] = {"ms": ms, "pairs_per_s": F / (ms * 1e-3), "ms_synchronous": ms_sync,
+                             "objects_per_frame": float(ws["n_objects"].float().mean()),
+                             "kernels_ms": {capi.STAGE_NAMES[i]: (t / n if n else None) for i, (t, n) in enumerate(st)
+                                            if i != capi.MOD_STAGE_CLUSTER_GROUP}}
+        ctx.close()
+        del ws, batch, d_now, d_prev, flow
+    return out
+
+
 def main():
     """Rank-level failures are fatal and visible: one line on stderr that names the rank, a non-zero exit code (the launcher then
     stops the other ranks and fails too), and no JSON line — the line is written last, by rank 0, after every rank's timed work."""
@@ -357,9 +413,10 @@ def run():
     for _ in range(args.warmup):
         ctx.process(batch, ws)
     torch.cuda.synchronize()
-    # Timed region: HIP events (on the stream the kernels run on) bracket only the kernel the roofline prices, the
-    # scene-flow kernel; event pairs around all seven kernel groups would cost the timed region ~8 % of stream time.
-    ctx.set_profiling(True, stages=[capi.MOD_STAGE_SCENE_FLOW])
+    # Timed region: HIP events (on the stream the kernels run on) bracket the kernel the roofline prices, the scene-flow kernel,
+    # and the cluster group as a whole (first launch to last: its chunks overlap, ModConfig.batch_chunks); event pairs around
+    # every kernel would cost the timed region ~8 % of stream time and keep the group from running in chunks.
+    ctx.set_profiling(True, stages=[capi.MOD_STAGE_SCENE_FLOW, capi.MOD_STAGE_CLUSTER_GROUP])
     ctx.reset_stage_times()
     barrier()
     torch.cuda.synchronize()
@@ -370,7 +427,9 @@ def run():
     barrier()
     elapsed = time.perf_counter() - t0
     sf_timed = ctx.stage_time(capi.MOD_STAGE_SCENE_FLOW)
-    # Untimed breakdown pass over the same batch: every kernel group bracketed (reported next to the roofline kernel).
+    cl_timed = ctx.stage_time(capi.MOD_STAGE_CLUSTER_GROUP)
+    # Untimed breakdown pass over the same batch: every kernel bracketed (reported next to the roofline kernel); with these
+    # timers on the call runs its cluster stage in ONE chunk, each kernel alone on the GPU.
     ctx.set_profiling(True)
     ctx.reset_stage_times()
     for _ in range(max(1, min(args.steps, 10))):
@@ -394,12 +453,14 @@ def run():
         ms = [(t / n if n else float("nan")) for t, n in stage]                 # average launch duration per kernel
         breakdown_sf_ms = ms[capi.MOD_STAGE_SCENE_FLOW]
         ms[capi.MOD_STAGE_SCENE_FLOW] = sf_timed[0] / sf_timed[1]               # the priced kernel: from the timed region
-        kernels = {capi.STAGE_NAMES[i]: ms[i] for i in range(capi.MOD_STAGE_COUNT)}
+        per_kernel = [capi.MOD_STAGE_SCENE_FLOW] + list(capi.MOD_PER_KERNEL_CLUSTER_STAGES)
+        kernels = {capi.STAGE_NAMES[i]: ms[i] for i in per_kernel}
         sf_ms = ms[capi.MOD_STAGE_SCENE_FLOW]
-        cl_ms = sum(ms[1:])
+        cl_sum_ms = sum(ms[i] for i in capi.MOD_PER_KERNEL_CLUSTER_STAGES)     # the group's kernels one after the other, each alone
+        cl_ms = cl_timed[0] / cl_timed[1]                                       # the group as the timed region ran it
         sf_gbs = F * N * B_SCENE_FLOW / (sf_ms * 1e-3) / 1e9
         cl_gbs = F * N * B_CLUSTER / (cl_ms * 1e-3) / 1e9
-        dom = max(range(capi.MOD_STAGE_COUNT), key=lambda i: ms[i])            # the single kernel with the longest launch
+        dom = max(per_kernel, key=lambda i: ms[i])                             # the single kernel with the longest launch
         # algorithmic bytes of that kernel per launch: the scene-flow kernel moves its group's 40 B/px; a cluster kernel is
         # priced with the whole cluster group's 20 B/px (the group's bytes are not separable per kernel)
         dom_bytes = F * N * (B_SCENE_FLOW if dom == capi.MOD_STAGE_SCENE_FLOW else B_CLUSTER)
@@ -427,7 +488,11 @@ def run():
             "kernels_ms_per_launch": kernels,
             "groups": {
                 "scene_flow": {"ms_per_launch": sf_ms, "GBps": sf_gbs, "frac": sf_gbs / HBM_PEAK_GBS, "bytes_per_px": B_SCENE_FLOW},
-                "cluster": {"ms_per_launch": cl_ms, "GBps": cl_gbs, "frac": cl_gbs / HBM_PEAK_GBS, "bytes_per_px": B_CLUSTER},
+                "cluster": {"ms_per_launch": cl_ms, "GBps": cl_gbs, "frac": cl_gbs / HBM_PEAK_GBS, "bytes_per_px": B_CLUSTER,
+                            "measured_in": "timed region: HIP events around the whole group, first launch to last (in chunks that overlap: "
+                                           "ModConfig.batch_chunks, include/mod_sf.h)",
+                            "kernels_one_after_the_other_ms": cl_sum_ms,
+                            "frac_kernels_one_after_the_other": F * N * B_CLUSTER / (cl_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "fused_end_to_end": {"GBps": F * N * B_FUSED / ((sf_ms + cl_ms) * 1e-3) / 1e9, "bytes_per_px": B_FUSED},
             },
         }
@@ -435,11 +500,18 @@ def run():
         planes = ws["planes"][:, :n_chk].cpu().numpy()   # the sampled pairs' outputs, for the same-run check against the oracle
         labels = ws["labels"][:n_chk].cpu().numpy() if ws["labels"] is not None else None
         c5 = c5_check = None
-        if not args.no_config5:
+        lat = None
+        if not args.no_latency or not args.no_config5:
             ctx.close()                                       # frees the 512-pair context's scratch before the SGM volumes come
             ctx._ws = None
             del batch, ws, d_now, d_prev, flow
             torch.cuda.empty_cache()
+        if not args.no_latency:                               # rank 0 alone, the group is down (like config 5 and the CPU baseline)
+            try:
+                lat = latency_leg(dev, local_rank, cam_s, prm_s, host, W, H)
+            except Exception as e:                            # noqa: BLE001  (outside `value`)
+                lat = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_config5:
             try:
                 c5, c5_check = config5_leg(dev, local_rank)
             except Exception as e:                            # noqa: BLE001  (the leg is outside `value`; its failure must not cost the line)
@@ -478,6 +550,8 @@ def run():
                        "collective_error": group_error},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if lat is not None:
+            line["latency"] = lat
         if c5 is not None:
             line["config5"] = c5
         emit(line)

@@ -32,7 +32,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define MOD_ABI_VERSION 1
+#define MOD_ABI_VERSION 2   /* 2: ModConfig.batch_chunks (was reserved), stage "select" folded into MOD_STAGE_CCL_MERGE, MOD_STAGE_CLUSTER_GROUP */
 
 /* status codes */
 #define MOD_OK                      0
@@ -59,7 +59,13 @@ typedef struct ModConfig {
   int32_t max_objects;  /* per-frame capacity of the ModObject output; 0 -> max_width*max_height/100 (Clusterer.cfg:8 lower bound).
                            mod_set_params rejects a cluster_size with max_width*max_height/cluster_size > max_objects, so no
                            cluster can ever be dropped */
-  int32_t reserved;
+  int32_t batch_chunks; /* mod_process_dev on a large batch: the cluster stage runs in this many chunks of frames (1..4), side by side
+                           on streams of the context's own, so that its waiting kernels (cross-tile links, root merge, median
+                           selection, tie replay) share the GPU with the streaming kernels of another chunk; forked from and joined
+                           to `stream` with events — the call is ordered on `stream` like any other.  0 -> the library's choice
+                           (2 chunks from 64 frames on; a chunk has at least 32 frames); 1 -> never.  Results do not depend on it.
+                           Bits 8 and 9 are measurement switches (tools/chunk_ab.py): cut the scene-flow kernel too / hold the
+                           chunks' kernel chains one kernel apart */
   void   *stream;       /* hipStream_t to enqueue on; NULL -> the context creates its own */
 } ModConfig;
 
@@ -311,10 +317,15 @@ int  mod_memcpy_d2h(ModContext *ctx, void *host_dst, const void *dev_src, uint64
 #define MOD_STAGE_CCL_TILE    1   /* tile stage: k_ccl_bits<n> + k_ccl_tile_list (k_ccl_tile for n > 10): tile-local
                                      connected components (+ k_dynamic_mask / k_tile_flags for a caller's cloud)  */
 #define MOD_STAGE_CCL_LINK    2   /* k_ccl_link: cross-tile unions                                              */
-#define MOD_STAGE_CCL_MERGE   3   /* k_ccl_merge: root-level flatten + record folding                           */
-#define MOD_STAGE_SELECT      4   /* k_select: size filter, reference numbering, bbox/centre                    */
-#define MOD_STAGE_FINAL       5   /* k_final: labels plane + member compaction                                  */
-#define MOD_STAGE_MEDIAN      6   /* k_median + k_median_ties + k_finalize: median-velocity member, object ids  */
+#define MOD_STAGE_CCL_MERGE   3   /* k_ccl_merge: root-level flatten + record folding; each frame's last workgroup
+                                     runs the size filter and the reference numbering (a kernel of its own, stage
+                                     "select", until ABI version 1)                                             */
+#define MOD_STAGE_FINAL       4   /* k_final: labels plane + member compaction + cluster boxes                  */
+#define MOD_STAGE_MEDIAN      5   /* k_median + k_median_ties: median-velocity member; object ids               */
+#define MOD_STAGE_CLUSTER_GROUP 6 /* the whole cluster stage of a call, first launch to last (stages 1..5 and, in a chunked
+                                     mod_process_dev, the overlap of its chunks: see ModConfig.batch_chunks).  While a timer
+                                     of one of the stages 1..5 is on, mod_process_dev runs un-chunked: side by side the kernels
+                                     of different chunks would be priced with each other's load */
 #define MOD_STAGE_COUNT       7
 #define MOD_PROFILE_ALL        0x7f
 int  mod_set_profiling(ModContext *ctx, int32_t stage_mask);

@@ -26,10 +26,12 @@ MOD_ERR_CAPACITY = -3
 MOD_ERR_DEVICE = -4
 MOD_ERR_NO_DEVICE = -5
 MOD_STAGE_SCENE_FLOW, MOD_STAGE_CCL_TILE, MOD_STAGE_CCL_LINK, MOD_STAGE_CCL_MERGE = 0, 1, 2, 3
-MOD_STAGE_SELECT, MOD_STAGE_FINAL, MOD_STAGE_MEDIAN, MOD_STAGE_COUNT = 4, 5, 6, 7
+MOD_STAGE_FINAL, MOD_STAGE_MEDIAN, MOD_STAGE_CLUSTER_GROUP, MOD_STAGE_COUNT = 4, 5, 6, 7
 MOD_PROFILE_ALL = 0x7F
+MOD_PER_KERNEL_CLUSTER_STAGES = (1, 2, 3, 4, 5)
 MOD_PIPELINE_DEPTH = 3
-STAGE_NAMES = ("k_scene_flow", "k_ccl_bits+k_ccl_tile_list", "k_ccl_link", "k_ccl_merge", "k_select", "k_final", "k_median+k_median_ties+k_finalize")
+STAGE_NAMES = ("k_scene_flow", "k_ccl_bits+k_ccl_tile_list", "k_ccl_link", "k_ccl_merge", "k_final", "k_median+k_median_ties",
+               "cluster group (first launch to last)")
 
 # every symbol include/mod_sf.h declares (tests check that the library exports all of them)
 EXPORTS = [
@@ -45,7 +47,7 @@ EXPORTS = [
 
 class ModConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_width", C.c_int32), ("max_height", C.c_int32), ("max_frames", C.c_int32),
-                ("max_objects", C.c_int32), ("reserved", C.c_int32), ("stream", C.c_void_p)]
+                ("max_objects", C.c_int32), ("batch_chunks", C.c_int32), ("stream", C.c_void_p)]
 
 
 class ModCamera(C.Structure):

@@ -19,12 +19,12 @@
 //                  are united with LDS atomicMin hooks; interior pixels publish parent[p] = tile root with plain stores, halo
 //                  pixels that were reached leave link requests; one partial statistics record per tile root.
 //   k_ccl_link     requests -> unions between tile roots (device-scope atomicMin hooks), one wave per tile.
-//   k_ccl_merge    every tile root finds its final root, folds its record into it; final roots are listed.
-//   k_select       size filter + ordering by first_edge_key (the reference's numbering) + bbox / centre; cluster work list.
+//   k_ccl_merge    every tile root finds its final root, folds its record into it; final roots are listed; the frame's last
+//                  workgroup runs the size filter + ordering by first_edge_key (the reference's numbering), cluster work list.
 //   k_final        labels plane + per-cluster member lists (||v|| bits, pixel).
 //   k_median       exact selection of the member at size/2 by ||v|| (norms held in registers, LDS histogram rounds);
-//   k_median_ties  replay of libstdc++'s introsort for clusters whose median ties between different vectors;
-//   k_finalize     object ids over the accepted clusters.
+//   k_median_ties  replay of libstdc++'s introsort for clusters whose median ties between different vectors; the launch's last
+//                  workgroup assigns the object ids over the accepted clusters and zeroes the counters for the next call.
 #include "mod_launch.h"
 #include <algorithm>
 #include <cstdlib>
@@ -50,6 +50,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ int ld_relaxed(const int *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+
+// device-scope store / load: to / from memory past the (per-XCD, mutually incoherent) L2s — how a workgroup reads, in the SAME kernel,
+// what a workgroup on another XCD has written (k_ccl_merge's last workgroup per frame)
+__device__ __forceinline__ void st_agent(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ int uf_find(const int *parent, int a) {
   int p = ld_relaxed(parent + a);
@@ -1095,8 +1100,10 @@ __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_
 // their final root), and folds its partial record into the final root's record; final roots list themselves for k_select.
 // A wave takes 64 / TH tiles at once: lane = (tile, row of the tile) reads that row's root bits and walks them — the few roots
 // of a row one after the other, all rows and tiles of the wave side by side (each root is a chain of dependent accesses).
+__device__ void select_frame(const DevCam &c, const ClArgs &a, ClusterInfo *tmp, int f, int tid);
+
 template <int TH>
-__global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles_per_frame) {
+__global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles_per_frame, ClusterInfo *tmp) {
   static_assert(64 % TH == 0, "a wave covers whole tiles");
   constexpr int TPW = 64 / TH;                         // tiles per wave
   const int f = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1104,10 +1111,10 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
   const size_t N = (size_t)c.W * c.H;
   int *parent = a.parent + (size_t)f * N;
   int *rsize = a.rsize + (size_t)f * N, *rkey = a.rkey + (size_t)f * N;
-  if (t >= tiles_per_frame || a.tilehdr[((size_t)f * tiles_per_frame + t) * 2] == 0) return;   // nothing dynamic in the tile
   const int wi = t % c.mask_words, ty = t / c.mask_words, y = ty * TH + j;
-  if (y >= c.H) return;
-  unsigned long long bits = a.lroot[((size_t)f * c.H + y) * c.mask_words + wi];
+  unsigned long long bits = 0ull;
+  if (t < tiles_per_frame && y < c.H && a.tilehdr[((size_t)f * tiles_per_frame + t) * 2] != 0)   // (0: nothing dynamic in the tile)
+    bits = a.lroot[((size_t)f * c.H + y) * c.mask_words + wi];
   while (bits) {
     const int b = __ffsll(bits) - 1;
     bits &= bits - 1ull;
@@ -1116,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
     if (!MOD_CHECK(a, r >= 0 && (size_t)r < N, 2)) continue;
     if (r == p) {
       const int slot = atomicAdd(&a.counters[f * 8 + 0], 1);
-      if (MOD_CHECK(a, slot >= 0 && (size_t)slot < N, 3)) a.rootlist[(size_t)f * N + slot] = p;
+      if (MOD_CHECK(a, slot >= 0 && (size_t)slot < N, 3)) st_agent(&a.rootlist[(size_t)f * N + slot], p);   // read by the frame's last workgroup
     } else {
       parent[p] = r;   // r is final: no union runs after k_ccl_link
       const int sz = rsize[p], ky = rkey[p];
@@ -1127,17 +1134,31 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
       if (ky != kKeyNone) atomicMin(&rkey[r], ky);
     }
   }
+  // The size filter needs every record of the frame folded: the frame's LAST workgroup to get here runs it (round 5; a kernel of its
+  // own until then — one dependent launch less per call, which is what a small batch is made of).  What it reads of the other
+  // workgroups' work went to memory past the XCD's L2 — device-scope atomics (counts, sizes, keys) and device-scope stores (the root
+  // list) — and has been acknowledged when the writer's waves pass the barrier below (it drains their memory counters); the last
+  // workgroup reads it with device-scope loads.  No fence: a device-scope release is a write-back of the XCD's whole L2, and one per
+  // workgroup made this kernel 20x slower (0.017 -> 0.36 ms per 64 pairs, measured).
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&a.counters[f * 8 + 2], 1) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;                                 // block-uniform
+  if (threadIdx.x == 0) a.counters[f * 8 + 2] = 0;     // (k_median_ties counts its workgroups in frame 0's slot)
+  select_frame(c, a, tmp, f, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One block per frame: size filter, ordering by first_edge_key, new labels, member-segment offsets, bbox/centre.
-__global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo *tmp) {
-  const int f = blockIdx.x, tid = threadIdx.x;
+// One workgroup of 256 threads per frame (the frame's last one in k_ccl_merge): size filter, ordering by first_edge_key, new labels,
+// member-segment offsets, object shells.  What other workgroups of the same kernel wrote (root list, records) is read past the
+// caches of this CU / XCD (ld_agent: device-scope loads).
+__device__ void select_frame(const DevCam &c, const ClArgs &a, ClusterInfo *tmp, int f, int tid) {
   __shared__ int s_n;
   if (tid == 0) s_n = 0;
   __syncthreads();
   const size_t N = (size_t)c.W * c.H;
-  const int nroots = a.counters[f * 8 + 0];
+  const int nroots = ld_agent(&a.counters[f * 8 + 0]);
   int *rsize = a.rsize + (size_t)f * N, *rkey = a.rkey + (size_t)f * N;
   const int *roots = a.rootlist + (size_t)f * N;
   ClusterInfo *T = tmp + (size_t)f * a.max_objects;
@@ -1145,9 +1166,9 @@ __global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo 
   // removeSmallClusters: `cluster_size.at(i) < cluster_size_th_` drops the component (clusterer_nodelet.cpp:374);
   // a component without any edge never got a label in the reference (key == none)
   for (int i = tid; i < nroots; i += 256) {
-    const int r = roots[i];
+    const int r = ld_agent(roots + i);
     if (!MOD_CHECK(a, r >= 0 && (size_t)r < N, 4)) continue;
-    const int size = rsize[r], key = rkey[r];
+    const int size = ld_agent(rsize + r), key = ld_agent(rkey + r);
     bool keep = (key != kKeyNone) && (size >= c.cluster_size);
     if (keep) {
       const int slot = atomicAdd(&s_n, 1);
@@ -1281,6 +1302,9 @@ __global__ __launch_bounds__(NW * 64) void k_final(DevCam c, ClArgs a) {
   };
   if (early) load_members();
   lds_barrier();
+  // every wave of the tile has read the header: the tile stage's last reader leaves it zero for the next call (the scene-flow
+  // epilogue / k_tile_flags only ever SET headers, so nobody has to clear 0.9 M of them per 512 pairs beforehand)
+  if (w == 0 && lane == 0) a.tilehdr[tidx * 2] = 0;
   // ---- labels ----
   const float invW = 1.0f / (float)c.W;
   const int tile0 = y0 * c.W + x0;
@@ -1742,7 +1766,24 @@ __device__ __forceinline__ void tie_narrow(KP key, KP val, PP Apos, PP Bpos, int
   }
 }
 
-__global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a) {
+// publishMovingObjects (clusterer_nodelet.cpp:324-343): ids run over ACCEPTED clusters only; a cluster is rejected when
+// (double)||median v|| < dynamic_speed (:176) — unreachable for members that are all dynamic, kept for exactness.
+__device__ __forceinline__ void finalize_frame(const DevCam &c, const ClArgs &a, int f) {
+  const int K = a.counters[f * 8 + 1];                 // (k_ccl_merge's, an earlier kernel)
+  ModObject *O = (ModObject *)a.objects + (size_t)f * a.max_objects;
+  const ClusterInfo *C = a.clusters + (size_t)f * a.max_objects;
+  int n = 0;
+  for (int k = 0; k < K; k++) {
+    const float nrm = __uint_as_float(C[k].med_bits);
+    if ((double)nrm < c.speed_th_d) continue;
+    if (n != k) O[n] = O[k];
+    O[n].id = n;
+    n++;
+  }
+  a.n_objects[f] = n;
+}
+
+__global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a, int frames) {
   using namespace introsort_emul;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t N = (size_t)c.W * c.H;
@@ -1902,29 +1943,22 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a)
       ci->med_pix = (int)best; ci->ambiguous = 2;    // 2 = tie resolved by replaying the reference's sort
       ModObject *o = (ModObject *)a.objects + (size_t)f * a.max_objects + k;
       o->velocity[0] = (double)a.vx[fN + best]; o->velocity[1] = (double)a.vy[fN + best]; o->velocity[2] = (double)a.vz[fN + best];
+      __threadfence();                               // device-wide before this workgroup's count below (rare path: once per tied cluster)
     }
     __syncthreads();
   }
-}
-
-// publishMovingObjects (clusterer_nodelet.cpp:324-343): ids run over ACCEPTED clusters only; a cluster is rejected when
-// (double)||median v|| < dynamic_speed (:176) — unreachable for members that are all dynamic, kept for exactness.
-__global__ void k_finalize(DevCam c, ClArgs a, int frames) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= frames) return;
-  const int K = a.counters[f * 8 + 1];
-  ModObject *O = (ModObject *)a.objects + (size_t)f * a.max_objects;
-  const ClusterInfo *C = a.clusters + (size_t)f * a.max_objects;
-  int n = 0;
-  for (int k = 0; k < K; k++) {
-    const float nrm = __uint_as_float(C[k].med_bits);
-    if ((double)nrm < c.speed_th_d) continue;
-    if (n != k) O[n] = O[k];
-    O[n].id = n;
-    n++;
-  }
-  a.counters[f * 8 + 2] = n;
-  a.n_objects[f] = n;
+  // ---- the launch's LAST workgroup to get here closes the call (round 5; k_finalize was a kernel of its own until then):
+  // publishMovingObjects for every frame, and the counters go back to zero — every call finds them as mod_create left them,
+  // no memset in front of the tile stage (mod_sf.hip: scratch_clean) ----
+  __shared__ int s_last;
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(&a.counters[2], 1) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;                                 // block-uniform
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the velocities other workgroups resolved (one invalidate per launch)
+  for (int f = tid; f < frames; f += kTieThreads) finalize_frame(c, a, f);
+  __syncthreads();                                     // (frame 0's thread has read its count before the words go)
+  for (int i = tid; i < frames * 8; i += kTieThreads) a.counters[i] = 0;
 }
 
 constexpr int kTileH = 16, kTileWaves = 4;   // tile = 64 x 16 px, 4 rows per wave (measured best of 8x4, 16x4, 16x8, 32x8)
@@ -1970,14 +2004,10 @@ void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
   const int tiles = (int)(g.x * g.y), per_block = kLinkTiles;
   hipLaunchKernelGGL(k_ccl_link, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles);
 }
-void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
+void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *rank_scratch, hipStream_t s) {
   const dim3 g = tile_grid(c, frames);
   const int tiles = (int)(g.x * g.y), per_block = 4 * (64 / kTileH);
-  hipLaunchKernelGGL(k_ccl_merge<kTileH>, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles);
-}
-void launch_select(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *tmp, hipStream_t s) {
-  // tmp: rank scratch, [frames][max_objects] like a.clusters
-  hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, tmp);
+  hipLaunchKernelGGL(k_ccl_merge<kTileH>, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles, rank_scratch);
 }
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // two waves per tile (8 rows each): 1 / 2 / 4 / 8 waves measured 1.419 (176 VGPRs: 2 waves per SIMD) / 0.965 / 1.001 / 1.460 ms per 512
@@ -1992,8 +2022,7 @@ void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) 
   // (round 5: two 64-VGPR workgroups fit a CU — 512 of them)
   hipLaunchKernelGGL(k_median, dim3(std::min(512, frames * 8)), dim3(kMedThreads), 0, s, c, a);
   if (!a.xy_from_z) hipLaunchKernelGGL(k_box_nan, dim3(std::min(64, frames * 2)), dim3(kMedThreads), 0, s, c, a);   // a caller's cloud may hold NaN coordinates
-  hipLaunchKernelGGL(k_median_ties, dim3(std::min(64, frames * 2)), dim3(kTieThreads), 0, s, c, a);
-  hipLaunchKernelGGL(k_finalize, dim3((frames + 63) / 64), dim3(64), 0, s, c, a, frames);
+  hipLaunchKernelGGL(k_median_ties, dim3(std::min(64, frames * 2)), dim3(kTieThreads), 0, s, c, a, frames);   // + publishMovingObjects in its last workgroup
 }
 
 int ccl_tile_rows() { return kTileH; }

@@ -32,8 +32,10 @@ struct ClArgs {
   int32_t *rkey;              // [F][N] its first_edge_key; after k_ccl_merge, at a tile root that is not final: its members' place inside the
                               // component's member segment; after k_select, at a final root: the new label, or -1
   ClusterBox *cbox;           // [F][max_objects] bounding boxes of the surviving clusters (k_select init, k_final atomics)
-  int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 n_objects; of frame 0 also (counts of the whole launch): 3 cursor into
-                              // `tilelist`, 4 its length, 5 k_median's cursor into `worklist`, 6 its length, 7 length of `tielist`
+  int32_t *counters;          // [F][8]: 0 n_comps, 1 n_clusters, 2 workgroups of k_ccl_merge done with the frame (of frame 0, later: of
+                              // k_median_ties done); of frame 0 also (counts of the whole launch): 3 cursor into `tilelist`, 4 its
+                              // length, 5 k_median's cursor into `worklist`, 6 its length, 7 length of `tielist`.  ALL ZERO between
+                              // calls: k_median_ties' last workgroup clears them
   ClusterInfo *clusters;      // [F][max_objects]
   uint32_t *mbits;            // [F][N] ||v|| bit patterns of the members, grouped per cluster (SoA with mpix)
   uint32_t *mpix;             // [F][N] pixel index of each member
@@ -46,13 +48,15 @@ struct ClArgs {
   int32_t xy_from_z;          // the planes are the fused scene-flow kernel's of this call: x, y of a valid pixel are functions of z
   uint2 *requests;            // [F][tiles][req_cap] cross-tile link requests (halo pixel, tile root)
   int32_t *tilehdr;           // [F][tiles][2]: 0 no dynamic pixel / 1 has one (set together with the mask words) / 2 done by k_ccl_bits;
-                              // number of requests
+                              // number of requests.  Word 0 is ZERO between calls: k_final, its last reader, clears it
   uint32_t *tilelist;         // [F * tiles] tiles that k_ccl_bits left to the union-find kernel (frame * tiles + tile)
   int32_t req_cap;
   unsigned long long *dbg;    // [96] diagnostic counters (mod_device.h): cycle counters when DevCam.debug & 128, index assertions of the checked build
 };
 
-void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s);
+// inline_consts: the frames' constants ride in the kernel arguments (frames <= MOD_SF_INLINE_FRAMES; a.fc is not read), or null
+#define MOD_SF_INLINE_FRAMES 8
+void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, const FrameConst *inline_consts, hipStream_t s);
 void launch_dynamic_mask(const DevCam &c, int frames, const float *vx, const float *vy, const float *vz, uint64_t *mask,
                          hipStream_t s);
 void launch_depth(const DevCam &c, int frames, const float *dnow, float *depth, hipStream_t s);
@@ -64,8 +68,7 @@ void launch_unpack(size_t n, const void *aos, float *x, float *y, float *z, floa
 void launch_ccl_tile(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 void launch_tile_flags(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);   // tile headers from a mask plane
 void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
-void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
-void launch_select(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *rank_scratch, hipStream_t s);
+void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *rank_scratch, hipStream_t s);   // + size filter
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 void launch_median(const DevCam &c, const ClArgs &a, int frames, hipStream_t s);
 int ccl_tile_rows();                 // tile height of k_ccl_tile

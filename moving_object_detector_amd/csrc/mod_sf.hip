@@ -17,6 +17,9 @@
 namespace {
 
 constexpr int kRing = 4;   // pinned staging slots for the per-frame constants
+constexpr int kMaxChunks = 4;       // mod_process_dev cuts a large batch into at most this many chunks (ModConfig.batch_chunks)
+constexpr int kChunkMinFrames = 32; // ... of at least this many frames each (a chunk must still fill the GPU on its own)
+constexpr int kAutoChunks = 2;      // ModConfig.batch_chunks == 0
 
 struct EventPair { hipEvent_t a, b; };
 
@@ -99,6 +102,15 @@ struct ModContext {
   FrameConst *pinned[kRing] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t pinned_ev[kRing] = {nullptr, nullptr, nullptr, nullptr};
   int ring_pos = 0;
+  // chunks of a large batch (process_chunked): chunk 0 runs on the context's stream, chunk k > 0 on chunk_stream[k - 1], forked from
+  // and joined to the context's stream with events, so the call keeps the stream semantics of every other entry point
+  hipStream_t chunk_stream[kMaxChunks - 1] = {};
+  hipEvent_t ev_fork = nullptr, ev_step[kMaxChunks] = {}, ev_join[kMaxChunks - 1] = {};
+  // The tile headers (word 0) and the cluster counters are ZERO between calls: mod_create clears them once, and the cluster stage's
+  // last readers (k_final; k_median_ties' last workgroup) clear what a call has set — two memsets less in front of every call, which
+  // a small batch feels (a launch costs it ~8 us of GPU time whatever it does).  False while a call is being enqueued; a call that
+  // failed half-way leaves it false and the next one clears the scratch itself.
+  bool scratch_clean = false;
   int profiling = 0;                          // stage mask of mod_set_profiling
   std::vector<EventPair> pending[MOD_STAGE_COUNT];
   std::vector<EventPair> free_events;
@@ -193,16 +205,16 @@ int check_ready(ModContext *c, int frames) {
 }
 
 struct StageTimer {
-  ModContext *c; int stage; EventPair ev{}; bool on;
-  StageTimer(ModContext *ctx, int st) : c(ctx), stage(st), on((ctx->profiling >> st) & 1) {
+  ModContext *c; int stage; hipStream_t s; EventPair ev{}; bool on;
+  StageTimer(ModContext *ctx, int st, hipStream_t stream) : c(ctx), stage(st), s(stream), on((ctx->profiling >> st) & 1) {
     if (!on) return;
     if (!c->free_events.empty()) { ev = c->free_events.back(); c->free_events.pop_back(); }
     else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
-    (void)hipEventRecord(ev.a, c->stream);
+    (void)hipEventRecord(ev.a, s);
   }
   ~StageTimer() {
     if (!on) return;
-    (void)hipEventRecord(ev.b, c->stream);
+    (void)hipEventRecord(ev.b, s);
     c->pending[stage].push_back(ev);
   }
 };
@@ -219,33 +231,42 @@ void drain_timers(ModContext *c) {
   }
 }
 
-int upload_frame_consts(ModContext *c, const ModFrameBatch *in) {
+void fill_frame_const(FrameConst &h, const ModTransform &tf, double dt) {
+  transform_to_rows(tf, h.m);
+  h.dt = dt;
+  // |t_i + (m_i0 x + (m_i1 y + m_i2 z))| <= tmax + 3 mmax B stays below FLT_MAX / 2 (so the F32 cast is finite, and no
+  // intermediate can overflow or turn NaN) for every |x|,|y|,|z| <= B.  Non-finite transforms get B = 0: always compute.
+  double mmax = 0.0, tmax = 0.0;
+  bool finite = true;
+  for (int i = 0; i < 12; i++) {
+    const double v = std::fabs(h.m[i]);
+    finite = finite && std::isfinite(v);
+    if (i % 4 == 3) tmax = std::max(tmax, v); else mmax = std::max(mmax, v);
+  }
+  double B = 0.0;
+  if (finite && tmax < 1e37) B = std::min((1.7e38 - tmax) / (3.0 * std::max(mmax, 1e-30)), 1e30);
+  h.pad[0] = B;
+  // velocity = difference / dt through the correctly rounded reciprocal (exact_div.h) when dt is an ordinary number
+  const bool usable = exact_div::reciprocal_usable(h.dt);
+  h.pad[1] = usable ? 1.0 / h.dt : 0.0;
+  h.pad[2] = usable ? 1.0 : 0.0;
+}
+
+// The per-frame constants of a batch.  Up to MOD_SF_INLINE_FRAMES frames: into `inl`, which the scene-flow launch passes in its
+// kernel arguments (returns true) — nothing is copied, nothing waited for.  Larger batches: through the pinned ring into c->b.fc.
+struct InlineConsts { FrameConst v[MOD_SF_INLINE_FRAMES]; bool used = false; };
+
+int upload_frame_consts(ModContext *c, const ModFrameBatch *in, InlineConsts *inl) {
+  if (inl && in->frames <= MOD_SF_INLINE_FRAMES) {
+    for (int f = 0; f < in->frames; f++) fill_frame_const(inl->v[f], in->transforms[f], in->dt[f]);
+    inl->used = true;
+    return MOD_OK;
+  }
   const int slot = c->ring_pos;
   c->ring_pos = (c->ring_pos + 1) % kRing;
   HIP_TRY(c, hipEventSynchronize(c->pinned_ev[slot]));   // the slot's previous copy has left the host buffer
   FrameConst *h = c->pinned[slot];
-  for (int f = 0; f < in->frames; f++) {
-    transform_to_rows(in->transforms[f], h[f].m);
-    h[f].dt = in->dt[f];
-    {
-      // |t_i + (m_i0 x + (m_i1 y + m_i2 z))| <= tmax + 3 mmax B stays below FLT_MAX / 2 (so the F32 cast is finite, and no
-      // intermediate can overflow or turn NaN) for every |x|,|y|,|z| <= B.  Non-finite transforms get B = 0: always compute.
-      double mmax = 0.0, tmax = 0.0;
-      bool finite = true;
-      for (int i = 0; i < 12; i++) {
-        const double v = std::fabs(h[f].m[i]);
-        finite = finite && std::isfinite(v);
-        if (i % 4 == 3) tmax = std::max(tmax, v); else mmax = std::max(mmax, v);
-      }
-      double B = 0.0;
-      if (finite && tmax < 1e37) B = std::min((1.7e38 - tmax) / (3.0 * std::max(mmax, 1e-30)), 1e30);
-      h[f].pad[0] = B;
-      // velocity = difference / dt through the correctly rounded reciprocal (exact_div.h) when dt is an ordinary number
-      const bool usable = exact_div::reciprocal_usable(h[f].dt);
-      h[f].pad[1] = usable ? 1.0 / h[f].dt : 0.0;
-      h[f].pad[2] = usable ? 1.0 : 0.0;
-    }
-  }
+  for (int f = 0; f < in->frames; f++) fill_frame_const(h[f], in->transforms[f], in->dt[f]);
   HIP_TRY(c, hipMemcpyAsync(c->b.fc, h, sizeof(FrameConst) * in->frames, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->pinned_ev[slot], c->stream));
   return MOD_OK;
@@ -263,64 +284,170 @@ int check_batch(ModContext *c, const ModFrameBatch *in) {
   return MOD_OK;
 }
 
-int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask, bool tile_flags, bool xy_optional) {
+int begin_cluster_scratch(ModContext *c) {
+  if (!c->scratch_clean) {
+    const size_t tiles = (size_t)c->max_mask_words * ((c->cfg.max_height + ccl_tile_rows() - 1) / ccl_tile_rows());
+    HIP_TRY(c, hipMemsetAsync(c->b.tilehdr, 0, sizeof(int32_t) * 2 * tiles * c->cfg.max_frames, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->b.counters, 0, sizeof(int32_t) * 8 * c->cfg.max_frames, c->stream));
+  }
+  c->scratch_clean = false;
+  return MOD_OK;
+}
+
+// frames [f0, f0 + n) of a batch: every per-frame pointer of the launch moves to the chunk's first frame, so that "frame 0 of the
+// launch" — where the clustering kernels keep their launch-wide counters and lists — is the chunk's own
+struct Chunk { int f0, n; };
+
+int check_scene_flow_out(ModContext *c, const ModSceneFlowPlanes *out, bool xy_optional) {
   if (!out || !out->z || !out->vx || !out->vy || !out->vz)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "scene-flow output planes z,vx,vy,vz are required");
   // x and y: both or neither; neither only where the call says so (mod_process_dev: the cluster stage recomputes them from z)
   if ((out->x == nullptr) != (out->y == nullptr) || (!out->x && !xy_optional))
     return fail(c, MOD_ERR_INVALID_ARGUMENT, xy_optional ? "scene-flow output planes x and y: pass both or neither" : "scene-flow output planes x,y,z,vx,vy,vz are required");
-  int rc = upload_frame_consts(c, in);
-  if (rc) return rc;
+  return MOD_OK;
+}
+
+// the scene-flow kernel over one chunk of the batch (the per-frame constants of the WHOLE batch are in c->b.fc by now)
+void enqueue_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask, bool tile_flags, Chunk ch,
+                        hipStream_t s, const InlineConsts *inl = nullptr) {
+  const size_t N = (size_t)c->dc.W * c->dc.H, f0 = (size_t)ch.f0, MWH = (size_t)c->dc.mask_words * c->dc.H;
   SfArgs a;
-  a.dnow = in->disparity_now; a.dprev = in->disparity_prev; a.flow = in->flow;
-  a.x = out->x; a.y = out->y; a.z = out->z; a.vx = out->vx; a.vy = out->vy; a.vz = out->vz;
-  a.mask = mask; a.aos = (float4 *)out->cloud_aos; a.depth = out->depth; a.sflow = out->static_flow;
-  a.fc = c->b.fc;
+  a.dnow = in->disparity_now + f0 * N; a.dprev = in->disparity_prev + f0 * N; a.flow = in->flow + f0 * N * 2;
+  a.x = out->x ? out->x + f0 * N : nullptr; a.y = out->y ? out->y + f0 * N : nullptr;
+  a.z = out->z + f0 * N; a.vx = out->vx + f0 * N; a.vy = out->vy + f0 * N; a.vz = out->vz + f0 * N;
+  a.mask = mask ? mask + f0 * MWH : nullptr;
+  a.aos = out->cloud_aos ? (float4 *)out->cloud_aos + f0 * N * 2 : nullptr;
+  a.depth = out->depth ? out->depth + f0 * N : nullptr;
+  a.sflow = out->static_flow ? out->static_flow + f0 * N * 2 : nullptr;
+  a.fc = c->b.fc + f0;
   a.tilehdr = nullptr; a.zrange = nullptr; a.tile_rows = ccl_tile_rows(); a.tiles_x = c->dc.mask_words;
   a.tiles_per_frame = c->dc.mask_words * ((c->dc.H + ccl_tile_rows() - 1) / ccl_tile_rows());
   a.dbg = c->b.dbg;
   if (tile_flags && mask) {      // the clustering follows: the kernel's epilogue also marks the cluster tiles that hold a dynamic pixel
-    a.tilehdr = c->b.tilehdr;
-    a.zrange = c->b.zrange;        // ... and leaves the depth range of every non-zero mask word's dynamic pixels for the tile stage
-    HIP_TRY(c, hipMemsetAsync(c->b.tilehdr, 0, sizeof(int32_t) * 2 * (size_t)a.tiles_per_frame * in->frames, c->stream));
+    a.tilehdr = c->b.tilehdr + f0 * 2 * (size_t)a.tiles_per_frame;   // (all zero: ModContext::scratch_clean)
+    a.zrange = c->b.zrange + f0 * MWH; // ... and leaves the depth range of every non-zero mask word's dynamic pixels for the tile stage
   }
-  {
-    StageTimer t(c, MOD_STAGE_SCENE_FLOW);
-    launch_scene_flow(c->dc, a, in->frames, c->stream);
-  }
+  StageTimer t(c, MOD_STAGE_SCENE_FLOW, s);
+  launch_scene_flow(c->dc, a, ch.n, (inl && inl->used) ? inl->v : nullptr, s);
+}
+
+int run_scene_flow(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *out, uint64_t *mask, bool tile_flags, bool xy_optional) {
+  int rc = check_scene_flow_out(c, out, xy_optional);
+  if (rc) return rc;
+  InlineConsts inl;
+  if ((rc = upload_frame_consts(c, in, &inl))) return rc;
+  enqueue_scene_flow(c, in, out, mask, tile_flags, Chunk{0, in->frames}, c->stream, &inl);   // (tile_flags: the caller has called begin_cluster_scratch)
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;
 }
 
-int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready, bool flags_ready,
-                const ModClusterOut *out) {
+int check_cluster_io(ModContext *c, const ModSceneFlowPlanes *pl, bool flags_ready, const ModClusterOut *out) {
   // flags_ready: the planes are this call's own scene-flow output (mod_process_dev), where x, y are functions of z and may be absent
   if (!pl || !pl->z || !pl->vx || !pl->vy || !pl->vz || (!flags_ready && (!pl->x || !pl->y)))
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster input planes x,y,z,vx,vy,vz are required");
   if (!out || !out->objects || !out->n_objects)
     return fail(c, MOD_ERR_INVALID_ARGUMENT, "cluster outputs objects, n_objects are required");
+  return MOD_OK;
+}
+
+// The clustering of one chunk on stream s.  `after_tile_stage` (optional) is recorded behind the chunk's tile stage: the next
+// chunk's tile stage waits for it (process_chunked).
+int enqueue_cluster(ModContext *c, Chunk ch, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready, bool flags_ready,
+                    const ModClusterOut *out, hipStream_t s, hipEvent_t after_tile_stage) {
+  const size_t N = (size_t)c->dc.W * c->dc.H, f0 = (size_t)ch.f0, MWH = (size_t)c->dc.mask_words * c->dc.H, MO = (size_t)c->max_objects;
+  const size_t tiles = (size_t)c->dc.mask_words * ((c->dc.H + ccl_tile_rows() - 1) / ccl_tile_rows());
+  const int frames = ch.n;
   ClArgs a;
-  a.x = pl->x; a.y = pl->y; a.z = pl->z; a.vx = pl->vx; a.vy = pl->vy; a.vz = pl->vz;
-  a.mask = mask; a.zrange = flags_ready ? c->b.zrange : nullptr; a.lroot = c->b.lroot; a.parent = c->b.parent; a.rootlist = (int32_t *)c->b.mpix;
-  a.labels = out->labels; a.rsize = c->b.rsize; a.rkey = c->b.rkey; a.cbox = c->b.cbox; a.counters = c->b.counters; a.clusters = c->b.clusters;
-  a.mbits = c->b.mbits; a.mpix = c->b.mpix; a.worklist = c->b.worklist; a.tielist = c->b.worklist + (size_t)c->cfg.max_frames * c->max_objects;
-  a.objects = out->objects; a.n_objects = out->n_objects;
-  a.n_clusters = out->n_clusters; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
+  a.x = pl->x ? pl->x + f0 * N : nullptr; a.y = pl->y ? pl->y + f0 * N : nullptr;
+  a.z = pl->z + f0 * N; a.vx = pl->vx + f0 * N; a.vy = pl->vy + f0 * N; a.vz = pl->vz + f0 * N;
+  a.mask = mask + f0 * MWH; a.zrange = flags_ready ? c->b.zrange + f0 * MWH : nullptr; a.lroot = c->b.lroot + f0 * MWH;
+  a.parent = c->b.parent + f0 * N; a.rootlist = (int32_t *)c->b.mpix + f0 * N;
+  a.labels = out->labels ? out->labels + f0 * N : nullptr; a.rsize = c->b.rsize + f0 * N; a.rkey = c->b.rkey + f0 * N;
+  a.cbox = c->b.cbox + f0 * MO; a.counters = c->b.counters + f0 * 8; a.clusters = c->b.clusters + f0 * MO;
+  a.mbits = c->b.mbits + f0 * N; a.mpix = c->b.mpix + f0 * N;
+  a.worklist = c->b.worklist + f0 * MO; a.tielist = c->b.worklist + (size_t)c->cfg.max_frames * MO + f0 * MO;
+  a.objects = (ModObject *)out->objects + f0 * MO; a.n_objects = out->n_objects + f0;
+  a.n_clusters = out->n_clusters ? out->n_clusters + f0 : nullptr; a.max_objects = c->max_objects; a.dbg = c->b.dbg;
   a.xy_from_z = flags_ready ? 1 : 0;                  // only mod_process_dev's fused path hands over its own scene-flow planes
-  a.requests = c->b.requests; a.tilehdr = c->b.tilehdr; a.tilelist = c->b.tilelist; a.req_cap = ccl_request_capacity(c->prm.neighbor_distance);
-  ClusterInfo *const rank_scratch = c->b.clusters + (size_t)c->cfg.max_frames * c->max_objects;   // second half of the allocation
+  const int req_cap = ccl_request_capacity(c->prm.neighbor_distance);
+  a.requests = c->b.requests + f0 * tiles * (size_t)req_cap; a.tilehdr = c->b.tilehdr + f0 * tiles * 2; a.tilelist = c->b.tilelist + f0 * tiles;
+  a.req_cap = req_cap;
+  ClusterInfo *const rank_scratch = c->b.clusters + (size_t)c->cfg.max_frames * MO + f0 * MO;   // second half of the allocation
   {
-    StageTimer t(c, MOD_STAGE_CCL_TILE);
-    if (!mask_ready) launch_dynamic_mask(c->dc, frames, pl->vx, pl->vy, pl->vz, (uint64_t *)mask, c->stream);
-    if (!flags_ready) launch_tile_flags(c->dc, a, frames, c->stream);
-    HIP_TRY(c, hipMemsetAsync(c->b.counters, 0, sizeof(int32_t) * 8 * frames, c->stream));
-    launch_ccl_tile(c->dc, a, frames, c->stream);
+    StageTimer t(c, MOD_STAGE_CCL_TILE, s);
+    if (!mask_ready) launch_dynamic_mask(c->dc, frames, a.vx, a.vy, a.vz, (uint64_t *)a.mask, s);
+    if (!flags_ready) launch_tile_flags(c->dc, a, frames, s);
+    launch_ccl_tile(c->dc, a, frames, s);                 // (the counters are zero: ModContext::scratch_clean)
   }
-  { StageTimer t(c, MOD_STAGE_CCL_LINK); launch_ccl_link(c->dc, a, frames, c->stream); }
-  { StageTimer t(c, MOD_STAGE_CCL_MERGE); launch_ccl_merge(c->dc, a, frames, c->stream); }
-  { StageTimer t(c, MOD_STAGE_SELECT); launch_select(c->dc, a, frames, rank_scratch, c->stream); }
-  { StageTimer t(c, MOD_STAGE_FINAL); launch_final(c->dc, a, frames, c->stream); }
-  { StageTimer t(c, MOD_STAGE_MEDIAN); launch_median(c->dc, a, frames, c->stream); }
+  if (after_tile_stage) HIP_TRY(c, hipEventRecord(after_tile_stage, s));
+  { StageTimer t(c, MOD_STAGE_CCL_LINK, s); launch_ccl_link(c->dc, a, frames, s); }
+  { StageTimer t(c, MOD_STAGE_CCL_MERGE, s); launch_ccl_merge(c->dc, a, frames, rank_scratch, s); }
+  { StageTimer t(c, MOD_STAGE_FINAL, s); launch_final(c->dc, a, frames, s); }
+  { StageTimer t(c, MOD_STAGE_MEDIAN, s); launch_median(c->dc, a, frames, s); }
+  return MOD_OK;
+}
+
+int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready, bool flags_ready,
+                const ModClusterOut *out) {
+  int rc = check_cluster_io(c, pl, flags_ready, out);
+  if (rc) return rc;
+  StageTimer t(c, MOD_STAGE_CLUSTER_GROUP, c->stream);
+  if ((rc = enqueue_cluster(c, Chunk{0, frames}, pl, mask, mask_ready, flags_ready, out, c->stream, nullptr))) return rc;
+  HIP_TRY(c, hipGetLastError());
+  return MOD_OK;
+}
+
+int ensure_chunk_streams(ModContext *c) {
+  if (c->ev_fork) return MOD_OK;
+  for (hipStream_t &q : c->chunk_stream) if (!q) HIP_TRY(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+  for (hipEvent_t &e : c->ev_step) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (hipEvent_t &e : c->ev_join) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  return MOD_OK;
+}
+
+// How many chunks a fused call of `frames` frames runs in (ModConfig.batch_chunks; mod_sf.h).  One chunk while a per-kernel
+// cluster timer is on: the kernels of different chunks run side by side, and a timer would price its kernel with its neighbours' load.
+int chunk_count(const ModContext *c, int frames) {
+  const int want = c->cfg.batch_chunks & 0xff;
+  const int per_kernel = ((1 << MOD_STAGE_CCL_TILE) | (1 << MOD_STAGE_CCL_LINK) | (1 << MOD_STAGE_CCL_MERGE) | (1 << MOD_STAGE_FINAL) |
+                          (1 << MOD_STAGE_MEDIAN));
+  if (c->profiling & per_kernel) return 1;
+  int n = want ? want : kAutoChunks;
+  n = std::min(n, kMaxChunks);
+  while (n > 1 && frames / n < kChunkMinFrames) n--;
+  return std::max(n, 1);
+}
+
+// mod_process_dev on a large batch.  The cluster stage ends in kernels that wait instead of moving bytes (cross-tile links, the root
+// merge + size filter, the median selection, the tie replay: a few workgroups chasing pointers) and begins with one that is bound by
+// workgroup dispatch (three quarters of the tiles are empty).  Cut into chunks of frames whose kernel chains run side by side on
+// streams of their own, the waiting kernels of one chunk share the GPU with the streaming kernels of another; the hardware
+// interleaves them as their workgroups come (measured, tools/chunk_ab.py, 512 pairs on three boxes: 2 chunks -2.9 / -1.6 / 0.0 %
+// of the step; chains held one kernel apart by events — bit 9 — -0.0 / +0.3 / -0.5 %; 3 chunks like 2).  The scene-flow kernel
+// stays ONE launch over the whole batch ahead of them: it is bandwidth-bound throughout and gains nothing from company (bit 8 cuts it
+// too: +0.5 ... +3 %, and its own time can then no longer be told from its neighbours').
+int process_chunked(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *pl, uint64_t *mask, const ModClusterOut *out, int C) {
+  const bool sf_chunked = (c->cfg.batch_chunks & 0x100) != 0, free_running = (c->cfg.batch_chunks & 0x200) == 0;
+  int rc = ensure_chunk_streams(c);
+  if (rc) return rc;
+  if ((rc = upload_frame_consts(c, in, nullptr))) return rc;
+  if (!sf_chunked) enqueue_scene_flow(c, in, pl, mask, true, Chunk{0, in->frames}, c->stream);
+  StageTimer group(c, MOD_STAGE_CLUSTER_GROUP, c->stream);
+  HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+  for (int k = 0; k < C; k++) {
+    const Chunk ch{(int)((int64_t)in->frames * k / C), (int)((int64_t)in->frames * (k + 1) / C - (int64_t)in->frames * k / C)};
+    hipStream_t s = k ? c->chunk_stream[k - 1] : c->stream;
+    if (k) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
+    if (k && !free_running) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_step[k - 1], 0));
+    if (sf_chunked) {
+      enqueue_scene_flow(c, in, pl, mask, true, ch, s);
+      HIP_TRY(c, hipEventRecord(c->ev_step[k], s));
+    }
+    if ((rc = enqueue_cluster(c, ch, pl, mask, true, true, out, s, sf_chunked ? nullptr : c->ev_step[k]))) return rc;
+    if (k) HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], s));
+  }
+  for (int k = 1; k < C; k++) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k - 1], 0));
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;
 }
@@ -342,6 +469,7 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   // launch geometry and index widths: frames ride in grid.y / grid.z (<= 65535), the scene-flow kernel addresses a frame's
   // planes with 32-bit byte offsets (32 B/px for the AoS cloud), cluster work items are frame * max_objects + cluster in 32 bits
   if (cfg->max_frames > 65535 || cfg->max_width > MOD_MAX_WIDTH) return MOD_ERR_INVALID_ARGUMENT;
+  if (cfg->batch_chunks < 0 || (cfg->batch_chunks & 0xff) > kMaxChunks || (cfg->batch_chunks & ~0x3ff)) return MOD_ERR_INVALID_ARGUMENT;
   if ((uint64_t)cfg->max_width * (uint64_t)cfg->max_height >= (1ull << 27)) return MOD_ERR_INVALID_ARGUMENT;
   if (cfg->max_objects > 0 && (uint64_t)cfg->max_objects * (uint64_t)cfg->max_frames >= (1ull << 31)) return MOD_ERR_INVALID_ARGUMENT;
   int ndev = 0;
@@ -380,6 +508,7 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   }
   ok &= dalloc(&c->b.dbg, kDbgWords) == hipSuccess;
   if (ok) ok &= hipMemset(c->b.dbg, 0, kDbgWords * 8) == hipSuccess;
+  // (tile headers and counters are cleared by the first call: scratch_clean starts false)
   if (ok) ok &= hipMemset((char *)c->b.dbg + 42 * 8, 0xFF, 8) == hipSuccess;   // slot 42 is a minimum
   for (int i = 0; i < kRing && ok; i++) {
     ok &= hipHostMalloc((void **)&c->pinned[i], sizeof(FrameConst) * F, hipHostMallocDefault) == hipSuccess;
@@ -425,6 +554,10 @@ void mod_destroy(ModContext *c) {
     if (c->b.sgm_fork[k]) (void)hipEventDestroy(c->b.sgm_fork[k]);
     for (hipEvent_t e : c->b.sgm_join[k]) if (e) (void)hipEventDestroy(e);
   }
+  for (hipStream_t q : c->chunk_stream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
+  for (hipEvent_t e : c->ev_step) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ev_join) if (e) (void)hipEventDestroy(e);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -539,16 +672,23 @@ int mod_cluster_dev(ModContext *c, int32_t frames, const ModSceneFlowPlanes *pl,
   int rc = check_ready(c, frames);
   if (rc) return rc;
   const bool have = pl && pl->dynamic_mask;
-  return run_cluster(c, frames, pl, have ? pl->dynamic_mask : c->b.mask, have, false, out);
+  if ((rc = check_cluster_io(c, pl, false, out)) || (rc = begin_cluster_scratch(c))) return rc;
+  if ((rc = run_cluster(c, frames, pl, have ? pl->dynamic_mask : c->b.mask, have, false, out))) return rc;
+  c->scratch_clean = true;
+  return MOD_OK;
 }
 
 int mod_process_dev(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *pl, const ModClusterOut *out) {
   int rc = check_batch(c, in);
   if (rc) return depth_on_skip(c, rc, in, pl);
   uint64_t *mask = (pl && pl->dynamic_mask) ? pl->dynamic_mask : c->b.mask;
-  rc = run_scene_flow(c, in, pl, mask, true, true);
+  const int chunks = chunk_count(c, in->frames);
+  if ((rc = check_scene_flow_out(c, pl, true)) || (rc = check_cluster_io(c, pl, true, out)) || (rc = begin_cluster_scratch(c))) return rc;
+  if (chunks > 1) rc = process_chunked(c, in, pl, mask, out, chunks);
+  else if (!(rc = run_scene_flow(c, in, pl, mask, true, true))) rc = run_cluster(c, in->frames, pl, mask, true, true, out);
   if (rc) return rc;
-  return run_cluster(c, in->frames, pl, mask, true, true, out);
+  c->scratch_clean = true;
+  return MOD_OK;
 }
 
 int mod_pack_cloud_dev(ModContext *c, int32_t frames, const ModSceneFlowPlanes *pl, void *aos) {
@@ -884,8 +1024,8 @@ int mod_cluster_cloud_host(ModContext *c, const void *cloud, int32_t width, int3
   HIP_TRY(c, hipGetLastError());
   ModClusterOut out{};
   out.labels = labels ? b.h_labels : nullptr; out.objects = b.h_objects; out.n_objects = b.h_nobj; out.n_clusters = b.h_nobj + 1;
-  rc = run_cluster(c, 1, &pl, c->b.mask, false, false, &out);
-  if (rc) return rc;
+  if ((rc = begin_cluster_scratch(c)) || (rc = run_cluster(c, 1, &pl, c->b.mask, false, false, &out))) return rc;
+  c->scratch_clean = true;
   return fetch_cluster_results(c, labels, objects, max_objects, n_objects);
 }
 

@@ -248,8 +248,29 @@ static_assert(kSfArgsAt == offsetof(SfKernargLayout, a), "SfArgs does not sit wh
 // Vector kernel: W % 4 == 0.  Block = 64 x 4 threads, thread = 4 consecutive pixels of a row, wave = 256 px of one row.
 // XY: the x and y planes are written (ModSceneFlowPlanes.x / .y given).  Two instances rather than a branch: the six-plane kernel's
 // instruction stream stays what it was (the kernel is sensitive to it: a wave-uniform `if (a.x)` around the two stores cost +1.6 %).
-template <bool XY>
-__global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
+// INL (small batches): the per-frame constants ride in the kernel arguments (SfConsts behind SfArgs: no copy from the host's pinned
+// ring in front of the kernel — a blit kernel plus the wait for it, 9 of a one-pair step's 100 us) and are read through the kernarg
+// pointer like the late arguments.  The kernels of large batches keep their signature and their instruction stream.
+constexpr int kSfInlineFrames = MOD_SF_INLINE_FRAMES;
+struct SfConsts { FrameConst v[kSfInlineFrames]; };
+struct SfKernargLayoutInl { DevCam c; SfArgs a; SfConsts k; };
+static_assert(std::is_trivially_copyable<SfConsts>::value && alignof(SfConsts) <= 8, "kernarg struct");
+template <bool INL> __device__ __forceinline__ FrameConst frame_const(const SfArgs &a, int f) {
+  if (INL) {
+    const SF_K4 char *kp = (const SF_K4 char *)__builtin_amdgcn_kernarg_segment_ptr();
+    const SF_K4 double *q = (const SF_K4 double *)(kp + offsetof(SfKernargLayoutInl, k) + (size_t)f * sizeof(FrameConst));
+    static_assert(sizeof(FrameConst) == 16 * sizeof(double), "FrameConst is 16 doubles");
+    FrameConst r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.m[i] = q[i];
+    r.dt = q[12]; r.pad[0] = q[13]; r.pad[1] = q[14]; r.pad[2] = q[15];
+    return r;
+  }
+  return a.fc[f];
+}
+
+template <bool XY, bool INL>
+__device__ __forceinline__ void sf_v4_body(const DevCam &c, const SfArgs &a) {
   const int lane = threadIdx.x;                      // 0..63
   // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs in dispatch order (x fastest), and each XCD has its
   // own L2.  Here XCD k takes every 8th ROW of blocks (4 image rows, all of their x blocks): the blocks in flight still cover ONE
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
   const size_t fN = (size_t)f * ((size_t)c.W * c.H);         // wave-uniform
   const uint32_t pix = (uint32_t)y * (uint32_t)c.W + (uint32_t)x0;
   const uint32_t o4 = pix * 4u, o8 = pix * 8u;
-  const FrameConst fc = a.fc[f];
+  const FrameConst fc = frame_const<INL>(a, f);
   uint32_t nib = 0;
   uint64_t *out_mask = nullptr;
   int32_t *out_hdr = nullptr;
@@ -381,9 +402,13 @@ __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) {
 }
 
 
+template <bool XY> __global__ __launch_bounds__(256) void k_scene_flow_v4(DevCam c, SfArgs a) { sf_v4_body<XY, false>(c, a); }
+template <bool XY> __global__ __launch_bounds__(256) void k_scene_flow_v4i(DevCam c, SfArgs a, SfConsts k) { sf_v4_body<XY, true>(c, a); }
+
 // Even widths that are not a multiple of 4 (the reference's own working resolution is 1242 x 376, detect_with_zed.launch:10):
 // rows are 8-byte aligned, so thread = 2 consecutive pixels (float2 loads / stores, one float4 of flow), wave = 128 px.
-__global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
+template <bool INL>
+__device__ __forceinline__ void sf_v2_body(const DevCam &c, const SfArgs &a) {
   const int lane = threadIdx.x;
   const int x0 = (blockIdx.x * 64 + lane) * 2;
   const int y = blockIdx.y * 4 + threadIdx.y;
@@ -392,7 +417,7 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
   const size_t fN = (size_t)f * ((size_t)c.W * c.H);
   const uint32_t pix = (uint32_t)y * (uint32_t)c.W + (uint32_t)x0;
   const uint32_t o4 = pix * 4u, o8 = pix * 8u;
-  const FrameConst fc = a.fc[f];
+  const FrameConst fc = frame_const<INL>(a, f);
   uint32_t two = 0;
   const float qnan = __uint_as_float(0x7fc00000u);
   float zmn = qnan, zmx = qnan;
@@ -454,8 +479,12 @@ __global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_scene_flow_v2(DevCam c, SfArgs a) { sf_v2_body<false>(c, a); }
+__global__ __launch_bounds__(256) void k_scene_flow_v2i(DevCam c, SfArgs a, SfConsts k) { sf_v2_body<true>(c, a); }
+
 // Scalar kernel for odd widths: thread = 1 pixel, wave = 64 px of one row.
-__global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) {
+template <bool INL>
+__device__ __forceinline__ void sf_v1_body(const DevCam &c, const SfArgs &a) {
   const int lane = threadIdx.x;
   const int x = blockIdx.x * 64 + lane;
   const int y = blockIdx.y * 4 + threadIdx.y;
@@ -463,7 +492,7 @@ __global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) {
   const bool inb = (x < c.W) && (y < c.H);
   const size_t N = (size_t)c.W * c.H;
   const size_t i = (size_t)f * N + (size_t)y * c.W + x;
-  const FrameConst fc = a.fc[f];
+  const FrameConst fc = frame_const<INL>(a, f);
   bool dyn = false;
   const float qnan = __uint_as_float(0x7fc00000u);
   float zmn = qnan, zmx = qnan;
@@ -489,6 +518,8 @@ __global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) {
     }
   }
 }
+__global__ __launch_bounds__(256) void k_scene_flow_v1(DevCam c, SfArgs a) { sf_v1_body<false>(c, a); }
+__global__ __launch_bounds__(256) void k_scene_flow_v1i(DevCam c, SfArgs a, SfConsts k) { sf_v1_body<true>(c, a); }
 
 // calculateDynamicMap alone (clusterer_nodelet.cpp:40-54) for clouds that did not come from the fused kernel.
 __global__ __launch_bounds__(256) void k_dynamic_mask(DevCam c, const float *__restrict__ vx, const float *__restrict__ vy,
@@ -535,18 +566,25 @@ __global__ __launch_bounds__(256) void k_unpack(size_t n, const float4 *aos, flo
 
 }  // namespace
 
-void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, hipStream_t s) {
+void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, const FrameConst *inline_consts, hipStream_t s) {
   dim3 block(64, 4, 1);
+  SfConsts k;
+  if (inline_consts) for (int f = 0; f < frames && f < kSfInlineFrames; f++) k.v[f] = inline_consts[f];   // (frames <= kSfInlineFrames)
   if ((c.W & 3) == 0) {
     dim3 grid((c.W / 4 + 63) / 64, (c.H + 3) / 4, frames);
-    if (a.x) hipLaunchKernelGGL(k_scene_flow_v4<true>, grid, block, 0, s, c, a);
+    if (inline_consts) {
+      if (a.x) hipLaunchKernelGGL(k_scene_flow_v4i<true>, grid, block, 0, s, c, a, k);
+      else hipLaunchKernelGGL(k_scene_flow_v4i<false>, grid, block, 0, s, c, a, k);
+    } else if (a.x) hipLaunchKernelGGL(k_scene_flow_v4<true>, grid, block, 0, s, c, a);
     else hipLaunchKernelGGL(k_scene_flow_v4<false>, grid, block, 0, s, c, a);
   } else if ((c.W & 1) == 0) {
     dim3 grid((c.W / 2 + 63) / 64, (c.H + 3) / 4, frames);
-    hipLaunchKernelGGL(k_scene_flow_v2, grid, block, 0, s, c, a);
+    if (inline_consts) hipLaunchKernelGGL(k_scene_flow_v2i, grid, block, 0, s, c, a, k);
+    else hipLaunchKernelGGL(k_scene_flow_v2, grid, block, 0, s, c, a);
   } else {
     dim3 grid((c.W + 63) / 64, (c.H + 3) / 4, frames);
-    hipLaunchKernelGGL(k_scene_flow_v1, grid, block, 0, s, c, a);
+    if (inline_consts) hipLaunchKernelGGL(k_scene_flow_v1i, grid, block, 0, s, c, a, k);
+    else hipLaunchKernelGGL(k_scene_flow_v1, grid, block, 0, s, c, a);
   }
 }
 

@@ -39,7 +39,7 @@ class Context:
     """One context per GPU / stream (single caller), like one SceneFlowConstructor + one ClustererNodelet."""
 
     def __init__(self, width: int, height: int, max_frames: int = 1, device: int = 0, max_objects: int = 0,
-                 use_torch_stream: bool = True):
+                 use_torch_stream: bool = True, batch_chunks: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("no HIP device visible: the MI355X path has no CPU fallback")
         self.lib = capi.load()
@@ -47,7 +47,7 @@ class Context:
         torch.cuda.set_device(self.device)
         self.width, self.height, self.max_frames = width, height, max_frames
         stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
-        cfg = capi.ModConfig(device, width, height, max_frames, max_objects, 0, stream)
+        cfg = capi.ModConfig(device, width, height, max_frames, max_objects, batch_chunks, stream)
         h = C.c_void_p()
         rc = self.lib.mod_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.mod_abi_version() == 1
+    assert lib.mod_abi_version() == 2
     # diagnostic entry points (csrc/mod_sf_debug.h) exist only in PHASE_COUNTERS / ABLATE builds
     assert not hasattr(lib, "mod_debug_read") and not hasattr(lib, "mod_debug_counters")
 

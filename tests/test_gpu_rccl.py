@@ -29,7 +29,7 @@ def test_bench_line_reports_the_collective_honestly(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "8", "--distinct", "4", "--steps", "2", "--warmup", "1",
-            "--no-cpu-baseline", "--no-config5"]
+            "--no-cpu-baseline", "--no-config5", "--no-latency"]
     r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     cfg = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["config"]

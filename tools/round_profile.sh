@@ -6,22 +6,22 @@ out=$PWD/gpurun_out/final
 rm -rf $out; mkdir -p $out
 timeout -k 10 500 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo "bench rc=$?"
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --workload pairs > $out/bench_pairs.json 2> $out/bench_pairs.err
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --frames 64 > $out/bench_64.json 2> $out/bench_64.err
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --camera kitti > $out/bench_kitti.json 2> $out/bench_kitti.err
-timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --workload nominal > $out/bench_nominal.json 2> $out/bench_nominal.err
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --workload pairs > $out/bench_pairs.json 2> $out/bench_pairs.err
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --frames 64 > $out/bench_64.json 2> $out/bench_64.err
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --camera kitti > $out/bench_kitti.json 2> $out/bench_kitti.err
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --workload nominal > $out/bench_nominal.json 2> $out/bench_nominal.err
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $repo/bench.py --no-cpu-baseline --no-config5 > $out/stats_bench.json 2> $out/stats.err
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $repo/bench.py --no-cpu-baseline --no-config5 --no-latency > $out/stats_bench.json 2> $out/stats.err
 echo "stats rc=$?"
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-config5 > $out/pmc_$ctr.json 2> $out/pmc_$ctr.err
+  timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-config5 --no-latency > $out/pmc_$ctr.json 2> $out/pmc_$ctr.err
   echo "$ctr rc=$?"
 done
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc_sq$i -- python3 $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config5 --frames 64 > $out/pmc_sq$i.json 2> $out/pmc_sq$i.err
+  timeout -k 10 400 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc_sq$i -- python3 $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-config5 --no-latency --frames 64 > $out/pmc_sq$i.json 2> $out/pmc_sq$i.err
   echo "sq$i rc=$?"
 done
 # on-GPU disparity: timings, config-5 end-to-end lines, kernel trace and SQ counters of tools/time_sgm.py

@@ -2,7 +2,7 @@ repo=$PWD
 cd /tmp && export TMPDIR=/tmp
 for i in 1 2 3; do
   out=$repo/gpurun_out/final_stats$i; rm -rf $out; mkdir -p $out
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $repo/bench.py --no-cpu-baseline --no-config5 > $out/bench.json 2> $out/err.log
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $repo/bench.py --no-cpu-baseline --no-config5 --no-latency > $out/bench.json 2> $out/err.log
   python3 - <<PY
 import csv,glob,json
 f=glob.glob('$out/*/*_kernel_stats.csv')[0]
