@@ -63,6 +63,12 @@ def parse():
                          "dt = 1/15 s, where the default uses 4-9 m, 1-2 m/s and 0.1 s (DESIGN.md section 10)")
     ap.add_argument("--no-labels", action="store_true",
                     help="do not produce the cluster-label plane (the reference renders its cluster image only for subscribers)")
+    ap.add_argument("--objects-only", action="store_true",
+                    help="the call of a node that serves ~moving_objects alone: no x / y planes (nobody takes the cloud, "
+                         "scene_flow_constructor.cpp:141-142) and no cluster-label plane; NOT the headline configuration")
+    ap.add_argument("--chunks", type=lambda v: int(v, 0), default=0,
+                    help="ModConfig.batch_chunks: 2..4 = cluster stage in that many chunks of frames side by side (worth 1-3 %% in a long run, "
+                         "nothing in a process's first calls: include/mod_sf.h); 0 / 1 = one piece (default)")
     ap.add_argument("--seed", type=int, default=4, help="scene seed of the synthetic stream")
     ap.add_argument("--no-dist", action="store_true",
                     help="N = 1 only: skip the process group (by default a one-rank RCCL group is brought up so that the single-GPU "
@@ -400,10 +406,12 @@ def run():
     flow.copy_(torch.from_numpy(np.ascontiguousarray(host["flow"])).to(dev)[idx])
     ts, qs, dts = host["t"][idx], host["q"][idx], host["dt"][idx]
 
-    ctx = Context(W, H, max_frames=F, device=local_rank)
+    if args.objects_only:
+        args.no_labels = True
+    ctx = Context(W, H, max_frames=F, device=local_rank, batch_chunks=args.chunks)
     ctx.set_camera(cam_s)
     ctx.set_params(prm_s)
-    ws = ctx.workspace(F, labels=not args.no_labels)
+    ws = ctx.workspace(F, labels=not args.no_labels, xy=not args.objects_only)
     batch = ctx.make_batch(d_now, d_prev, flow, ts, qs, dts)
 
     def barrier():
@@ -414,8 +422,8 @@ def run():
         ctx.process(batch, ws)
     torch.cuda.synchronize()
     # Timed region: HIP events (on the stream the kernels run on) bracket the kernel the roofline prices, the scene-flow kernel,
-    # and the cluster group as a whole (first launch to last: its chunks overlap, ModConfig.batch_chunks); event pairs around
-    # every kernel would cost the timed region ~8 % of stream time and keep the group from running in chunks.
+    # and the cluster group as a whole (first launch to last); event pairs around every kernel would cost the timed region ~8 %
+    # of stream time (and keep a --chunks run from running in chunks).
     ctx.set_profiling(True, stages=[capi.MOD_STAGE_SCENE_FLOW, capi.MOD_STAGE_CLUSTER_GROUP])
     ctx.reset_stage_times()
     barrier()
@@ -453,6 +461,10 @@ def run():
         ms = [(t / n if n else float("nan")) for t, n in stage]                 # average launch duration per kernel
         breakdown_sf_ms = ms[capi.MOD_STAGE_SCENE_FLOW]
         ms[capi.MOD_STAGE_SCENE_FLOW] = sf_timed[0] / sf_timed[1]               # the priced kernel: from the timed region
+        # the bytes of the planes a non-headline call does not produce are not priced either
+        B_SCENE_FLOW = 40 - (8 if args.objects_only else 0)
+        B_CLUSTER = 20 - (4 if args.no_labels else 0)
+        B_FUSED = 44 - (8 if args.objects_only else 0) - (4 if args.no_labels else 0)
         per_kernel = [capi.MOD_STAGE_SCENE_FLOW] + list(capi.MOD_PER_KERNEL_CLUSTER_STAGES)
         kernels = {capi.STAGE_NAMES[i]: ms[i] for i in per_kernel}
         sf_ms = ms[capi.MOD_STAGE_SCENE_FLOW]
@@ -480,7 +492,7 @@ def run():
             "frames_per_launch": F, "avg_launch_ms": ms[dom],
             "measured_in": "timed region" if dom == capi.MOD_STAGE_SCENE_FLOW else "breakdown pass (all stage timers on)",
             "scene_flow_ms_in_breakdown_pass": breakdown_sf_ms, "frac_of_measured_copy_ceiling": ach / HBM_COPY_GBS,
-            "frac_of_measured_read_write_bound": (ach / SF_RW_BOUND_GBS) if dom == capi.MOD_STAGE_SCENE_FLOW else None,
+            "frac_of_measured_read_write_bound": (ach / SF_RW_BOUND_GBS) if (dom == capi.MOD_STAGE_SCENE_FLOW and not args.objects_only) else None,
             "traffic_from_committed_profile": traffic is not None,       # a separate rocprofv3 --pmc run of this command, not this run
             "traffic_source": (f"profiles/{os.path.basename(tpath)} at commit {tj.get('head', '?')} (rocprofv3 --pmc FETCH_SIZE x2 on gfx950 + "
                                f"WRITE_SIZE in separate passes of this same command; counters cannot be read inside the run)"
@@ -489,8 +501,8 @@ def run():
             "groups": {
                 "scene_flow": {"ms_per_launch": sf_ms, "GBps": sf_gbs, "frac": sf_gbs / HBM_PEAK_GBS, "bytes_per_px": B_SCENE_FLOW},
                 "cluster": {"ms_per_launch": cl_ms, "GBps": cl_gbs, "frac": cl_gbs / HBM_PEAK_GBS, "bytes_per_px": B_CLUSTER,
-                            "measured_in": "timed region: HIP events around the whole group, first launch to last (in chunks that overlap: "
-                                           "ModConfig.batch_chunks, include/mod_sf.h)",
+                            "measured_in": "timed region: HIP events around the whole group, first launch to last"
+                                           + (f" (in {args.chunks & 0xff} chunks side by side: ModConfig.batch_chunks)" if (args.chunks & 0xff) > 1 else ""),
                             "kernels_one_after_the_other_ms": cl_sum_ms,
                             "frac_kernels_one_after_the_other": F * N * B_CLUSTER / (cl_sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
                 "fused_end_to_end": {"GBps": F * N * B_FUSED / ((sf_ms + cl_ms) * 1e-3) / 1e9, "bytes_per_px": B_FUSED},
@@ -498,6 +510,7 @@ def run():
         }
         n_chk = min(args.cpu_sample, G)
         planes = ws["planes"][:, :n_chk].cpu().numpy()   # the sampled pairs' outputs, for the same-run check against the oracle
+        checked_planes = [i for i, k in enumerate(PLANES) if not (args.objects_only and k in ("x", "y"))]
         labels = ws["labels"][:n_chk].cpu().numpy() if ws["labels"] is not None else None
         c5 = c5_check = None
         lat = None
@@ -524,8 +537,8 @@ def run():
             for f, (ref, lab, objs) in enumerate(refs):
                 if f >= n_chk:
                     break
-                for i, k in enumerate(PLANES):
-                    a, r = planes[i, f], ref[k]
+                for i in checked_planes:
+                    a, r = planes[i, f], ref[PLANES[i]]
                     ok &= bool(((a.view(np.uint32) == r.view(np.uint32)) | (np.isnan(a) & np.isnan(r))).all())
                 if labels is not None:
                     ok &= bool(np.array_equal(labels[f], lab))
@@ -538,7 +551,9 @@ def run():
             "config": {"workload": f"{W}x{H} synthetic sequence ({args.camera}-style camera), scene-flow + cluster kernels only (disparity/flow precomputed, "
                                    f"HBM-resident), reference default parameters",
                        "frames_per_step_per_gpu": F, "distinct_frames_per_gpu": G,
-                       "outputs": "six cloud planes, dynamic mask, objects" + ("" if args.no_labels else ", cluster-label plane"),
+                       "outputs": ("z + velocity planes, dynamic mask, objects (objects-only call: no x / y planes)" if args.objects_only
+                                   else "six cloud planes, dynamic mask, objects") + ("" if args.no_labels else ", cluster-label plane"),
+                       "batch_chunks": args.chunks,
                        "stream": ("one synthetic stream, contiguous chunk per rank + one disparity plane of halo" if args.workload == "sequence"
                                   else "the same with SURVEY.md 8(d)'s nominal object depth 4-15 m, speed 0.5-2 m/s, dt 1/15 s" if args.workload == "nominal"
                                   else "independent synthetic pairs per rank"),

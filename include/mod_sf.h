@@ -59,11 +59,12 @@ typedef struct ModConfig {
   int32_t max_objects;  /* per-frame capacity of the ModObject output; 0 -> max_width*max_height/100 (Clusterer.cfg:8 lower bound).
                            mod_set_params rejects a cluster_size with max_width*max_height/cluster_size > max_objects, so no
                            cluster can ever be dropped */
-  int32_t batch_chunks; /* mod_process_dev on a large batch: the cluster stage runs in this many chunks of frames (1..4), side by side
+  int32_t batch_chunks; /* mod_process_dev on a large batch: 2..4 -> the cluster stage runs in that many chunks of frames, side by side
                            on streams of the context's own, so that its waiting kernels (cross-tile links, root merge, median
                            selection, tie replay) share the GPU with the streaming kernels of another chunk; forked from and joined
-                           to `stream` with events — the call is ordered on `stream` like any other.  0 -> the library's choice
-                           (2 chunks from 64 frames on; a chunk has at least 32 frames); 1 -> never.  Results do not depend on it.
+                           to `stream` with events — the call is ordered on `stream` like any other; a chunk has at least 32 frames.
+                           0 or 1 -> one piece (the default).  Results do not depend on it.  Worth 1 - 3 % of a 512-pair step in a
+                           long-running process and nothing in a process's first calls (csrc/mod_sf.hip process_chunked).
                            Bits 8 and 9 are measurement switches (tools/chunk_ab.py): cut the scene-flow kernel too / hold the
                            chunks' kernel chains one kernel apart */
   void   *stream;       /* hipStream_t to enqueue on; NULL -> the context creates its own */

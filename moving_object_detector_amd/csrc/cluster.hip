@@ -1641,7 +1641,8 @@ __global__ __launch_bounds__(kMedThreads) void k_box_nan(DevCam c, ClArgs a) {
 // not after it, so ranks from two prefix counts give every swap at once — and the finished (<= 16 element) range gets the
 // stable insertion sort.  Rare path: one workgroup per flagged cluster, nothing to do for the others.
 // Scratch (all dead by now): keys -> parent plane, pixels -> rsize plane, swap lists -> the member arrays.
-constexpr int kTieThreads = 1024, kTieLds = 8192;
+constexpr int kTieThreads = 1024, kTieLds = 8192;   // (13 Ki elements = 156 KB, one partition level less in HBM: measured in round 5, no faster, and a
+                                                     // workgroup that needs a whole CU's LDS waits for one beside the other chunk's kernels)
 
 struct TieShared {           // control block of one workgroup of k_median_ties
   int cntA[kTieThreads / 64], cntB[kTieThreads / 64];
@@ -1873,10 +1874,12 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a,
         }
         __syncthreads();
         TSTAMP(21)
-        {   // exclusive prefix of the cell populations; thread t owns cells 8t .. 8t+7
-          int cnt[8], tot = 0;
+        {   // exclusive prefix of the cell populations; thread t owns cells CPT t .. CPT t + CPT - 1
+          constexpr int CPT = kTieLds / kTieThreads;
+          static_assert(CPT * kTieThreads == kTieLds, "every thread owns the same number of cells");
+          int cnt[CPT], tot = 0;
 #pragma unroll
-          for (int u = 0; u < 8; u++) { const int ci2 = tid * 8 + u; cnt[u] = ci2 < ncl ? __popcll((unsigned long long)cmask[ci2]) : 0; tot += cnt[u]; }
+          for (int u = 0; u < CPT; u++) { const int ci2 = tid * CPT + u; cnt[u] = ci2 < ncl ? __popcll((unsigned long long)cmask[ci2]) : 0; tot += cnt[u]; }
           int incl = tot;
           for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
           if (lane == 63) sh.cntA[wv] = incl;
@@ -1885,7 +1888,7 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a,
           __syncthreads();
           int run = sh.cntA[wv] + incl - tot;
 #pragma unroll
-          for (int u = 0; u < 8; u++) { cstart[tid * 8 + u] = (uint32_t)run; run += cnt[u]; }
+          for (int u = 0; u < CPT; u++) { cstart[tid * CPT + u] = (uint32_t)run; run += cnt[u]; }
           base = sh.cntB[0];
         }
         __syncthreads();

@@ -19,7 +19,7 @@ namespace {
 constexpr int kRing = 4;   // pinned staging slots for the per-frame constants
 constexpr int kMaxChunks = 4;       // mod_process_dev cuts a large batch into at most this many chunks (ModConfig.batch_chunks)
 constexpr int kChunkMinFrames = 32; // ... of at least this many frames each (a chunk must still fill the GPU on its own)
-constexpr int kAutoChunks = 2;      // ModConfig.batch_chunks == 0
+constexpr int kAutoChunks = 1;      // ModConfig.batch_chunks == 0: one piece (see process_chunked for what two chunks gain, and when)
 
 struct EventPair { hipEvent_t a, b; };
 
@@ -403,6 +403,15 @@ int ensure_chunk_streams(ModContext *c) {
   for (hipEvent_t &e : c->ev_step) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t &e : c->ev_join) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  // a few fork / join rounds, once: the runtime builds the cross-stream signalling of the new streams here, not inside the first call
+  for (int i = 0; i < 16; i++) {
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int k = 0; k < kMaxChunks - 1; k++) {
+      HIP_TRY(c, hipStreamWaitEvent(c->chunk_stream[k], c->ev_fork, 0));
+      HIP_TRY(c, hipEventRecord(c->ev_join[k], c->chunk_stream[k]));
+      HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
+    }
+  }
   return MOD_OK;
 }
 
@@ -419,14 +428,19 @@ int chunk_count(const ModContext *c, int frames) {
   return std::max(n, 1);
 }
 
-// mod_process_dev on a large batch.  The cluster stage ends in kernels that wait instead of moving bytes (cross-tile links, the root
-// merge + size filter, the median selection, the tie replay: a few workgroups chasing pointers) and begins with one that is bound by
-// workgroup dispatch (three quarters of the tiles are empty).  Cut into chunks of frames whose kernel chains run side by side on
-// streams of their own, the waiting kernels of one chunk share the GPU with the streaming kernels of another; the hardware
-// interleaves them as their workgroups come (measured, tools/chunk_ab.py, 512 pairs on three boxes: 2 chunks -2.9 / -1.6 / 0.0 %
-// of the step; chains held one kernel apart by events — bit 9 — -0.0 / +0.3 / -0.5 %; 3 chunks like 2).  The scene-flow kernel
-// stays ONE launch over the whole batch ahead of them: it is bandwidth-bound throughout and gains nothing from company (bit 8 cuts it
-// too: +0.5 ... +3 %, and its own time can then no longer be told from its neighbours').
+// mod_process_dev on a large batch, cluster stage in chunks (ModConfig.batch_chunks >= 2; opt-in).  The cluster stage ends in kernels
+// that wait instead of moving bytes (cross-tile links, the root merge + size filter, the median selection, the tie replay: a few
+// workgroups chasing pointers) and begins with one that is bound by workgroup dispatch (three quarters of the tiles are empty).  Cut
+// into chunks of frames whose kernel chains run side by side on streams of their own, the waiting kernels of one chunk share the GPU
+// with the streaming kernels of another; the hardware interleaves them as their workgroups come.  Measured (round 5, 512 pairs,
+// profiles/README.md): in a process that has been running for a second or more, 2 chunks take 0.7 - 2.9 % off the step (in-process
+// A/B on four boxes: tools/chunk_ab.py, tools/step_trace.py; bench.py --steps 200 --warmup 50: 5.11 - 5.18 vs 5.23 ms); in the first
+// ~25 calls of a fresh process they ADD 2 % (bench.py --steps 20 --warmup 5: 5.28 - 5.31 vs 5.15 - 5.21 ms) — the first calls show
+// hitches of ~0.9 ms each (the host falls behind while the runtime grows what the new streams need; a burst of fills and fork /
+// join rounds at stream creation did not remove them).  Hence not the default.  Chains held one kernel apart by events (bit 9):
+// no better than free-running ones; 3 or 4 chunks like 2.  The scene-flow kernel stays ONE launch over the whole batch ahead of
+// the chunks: it is bandwidth-bound throughout and gains nothing from company (bit 8 cuts it too: +0.5 ... +3 %, and its own time
+// can then no longer be told from its neighbours').
 int process_chunked(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *pl, uint64_t *mask, const ModClusterOut *out, int C) {
   const bool sf_chunked = (c->cfg.batch_chunks & 0x100) != 0, free_running = (c->cfg.batch_chunks & 0x200) == 0;
   int rc = ensure_chunk_streams(c);
@@ -1273,6 +1287,15 @@ int mod_debug_counters(ModContext *c, unsigned long long *out32) {
 int mod_set_profiling(ModContext *c, int32_t stage_mask) {
   if (!c || (stage_mask & ~MOD_PROFILE_ALL)) return MOD_ERR_INVALID_ARGUMENT;
   c->profiling = stage_mask;
+  // events for the next 64 calls are created here, not inside the calls that are being timed (an event pair costs tens of
+  // microseconds to create; later calls create what they lack)
+  const size_t want = (size_t)64 * (size_t)__builtin_popcount((unsigned)stage_mask);
+  while (c->free_events.size() < want) {
+    EventPair ev{};
+    if (hipEventCreate(&ev.a) != hipSuccess) break;
+    if (hipEventCreate(&ev.b) != hipSuccess) { (void)hipEventDestroy(ev.a); break; }
+    c->free_events.push_back(ev);
+  }
   return MOD_OK;
 }
 int mod_get_stage_time(ModContext *c, int32_t stage, double *total_ms, int64_t *calls) {

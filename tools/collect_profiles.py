@@ -40,20 +40,25 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             m = re.search(r"(k_\w+)", r["Kernel_Name"])
             if not m: continue
             agg[m.group(1)][0] += 1; agg[m.group(1)][1] += float(r["Counter_Value"])
-    for k, (n, v) in agg.items(): per[k][ctr] = v / n
+    # per STEP, not per launch: a chunked call (ModConfig.batch_chunks) launches every cluster kernel once per chunk; the scene-flow
+    # kernel runs once per step, so its launch count is the number of steps
+    steps = max(n for k, (n, v) in agg.items() if k.startswith("k_scene_flow"))
+    for k, (n, v) in agg.items(): per[k][ctr] = v / steps; per[k]["launches_per_step"] = n / steps
 for k, d in per.items():
     fetch = d.get("FETCH_SIZE", 0.0) * 1024 * 2
     write = d.get("WRITE_SIZE", 0.0) * 1024
     name = "k_scene_flow" if k.startswith("k_scene_flow") else k
-    traffic["kernels"][name] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
+    traffic["kernels"][name] = {"fetch_bytes_corrected": fetch, "write_bytes": write, "hbm_bytes_per_launch": fetch + write,   # (per step)
+                                "launches_per_step": d.get("launches_per_step"),
                                 "raw_FETCH_SIZE": d.get("FETCH_SIZE"), "raw_WRITE_SIZE": d.get("WRITE_SIZE")}
 json.dump(traffic, open(f"profiles/{tag.split('_')[0]}_traffic.json", "w"), indent=1)
 # extra bench lines + SQ counters (64-frame dispatches) of the two main kernels
 extra = {}
-for name in ("pairs", "64", "kitti", "nominal"):
+for name in ("pairs", "64", "kitti", "nominal", "objects_only", "chunks1", "chunks2", "chunks1_long", "chunks2_long"):
     try:
         j = json.loads(open(f"{src}/bench_{name}.json").read().strip().splitlines()[-1])
-        extra[name] = {"value": j["value"], "ms_per_step": j["ms_per_step"], "frames_per_step": j["config"]["frames_per_step_per_gpu"],
+        extra[name] = {"value": j["value"], "ms_per_step": j["ms_per_step"], "steps": j["steps"], "warmup": j["warmup"], "frames_per_step": j["config"]["frames_per_step_per_gpu"],
+                       "cluster_group_ms": j["roofline"]["groups"]["cluster"]["ms_per_launch"], "cluster_group_frac": j["roofline"]["groups"]["cluster"]["frac"],
                        "scene_flow_frac": j["roofline"]["groups"]["scene_flow"]["frac"], "kernels_ms_per_launch": j["roofline"]["kernels_ms_per_launch"]}
     except Exception as e:
         extra[name] = {"error": str(e)}
@@ -66,7 +71,24 @@ for d in sorted(glob.glob(f"{src}/pmc_sq*")):
             m = re.search(r"(k_scene_flow\w*|k_ccl_bits|k_ccl_tile_list|k_ccl_tile|k_final|k_median\b|k_ccl_link)", r["Kernel_Name"])
             if m: agg[(m.group(1), r["Counter_Name"])][0] += 1; agg[(m.group(1), r["Counter_Name"])][1] += float(r["Counter_Value"])
     for (k, cn), (n, v) in agg.items(): sq[k][cn] = v / n
-json.dump({"other_bench_lines": extra, "sq_counters_per_64_frame_dispatch": sq}, open(f"profiles/{tag}_extra.json", "w"), indent=1)
+def effective_clocks(d, pat):
+    """GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time per kernel (GHz), from one rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace pass."""
+    out = {}
+    try:
+        cc = max(glob.glob(f"{d}/*/*counter_collection.csv"), key=os.path.getmtime)
+        acc = collections.defaultdict(lambda: [0.0, 0.0, 0])
+        for r in csv.DictReader(open(cc)):
+            m = re.search(pat, r["Kernel_Name"])
+            if not m or r["Counter_Name"] != "GRBM_GUI_ACTIVE": continue
+            dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            if dur < 3e5: continue                      # the quotient reads high on dispatches shorter than ~0.3 ms
+            a = acc[m.group(1)]; a[0] += float(r["Counter_Value"]); a[1] += dur; a[2] += 1
+        for k, (cyc, ns, n) in acc.items(): out[k] = {"GHz": cyc / 8.0 / ns, "dispatches": n, "avg_us": ns / n / 1e3}
+    except Exception as e:
+        out["error"] = str(e)
+    return out
+clk = effective_clocks(f"{src}/pmc_clk", r"(k_scene_flow\w*|k_ccl_bits|k_final|k_median\b)")
+json.dump({"other_bench_lines": extra, "sq_counters_per_64_frame_dispatch": sq, "effective_clock": clk}, open(f"profiles/{tag}_extra.json", "w"), indent=1)
 # on-GPU disparity: timings, config-5 lines, per-kernel averages and SQ counters (per dispatch of one group of 8 frames)
 sgm = {"timings": [], "config5": {}, "kernels_avg_us": {}, "sq_counters_per_dispatch": {}}
 for name in ("sgm_720.log", "sgm_1080.log"):
@@ -88,6 +110,7 @@ try:
     for (k, cn), (n, v) in agg.items(): sgm["sq_counters_per_dispatch"].setdefault(k, {})[cn] = v / n
 except Exception as e:
     sgm["error"] = str(e)
+sgm["effective_clock"] = effective_clocks(f"{src}/sgm_clk", r"(k_sgm_\w+)")
 json.dump(sgm, open(f"profiles/{tag}_sgm.json", "w"), indent=1)
 print("value", bench["value"], "pairs/s;", bench["roofline"]["kernel"], "frac", round(bench["roofline"]["frac"], 3))
 for r in rows:

@@ -18,6 +18,9 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-config5 --no-latency > $out/pmc_$ctr.json 2> $out/pmc_$ctr.err
   echo "$ctr rc=$?"
 done
+# effective clock per kernel (MI355X_MICROARCH.md "DVFS give-back": GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time)
+timeout -k 10 400 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/pmc_clk -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-config5 --no-latency > $out/pmc_clk.json 2> $out/pmc_clk.err
+echo "clk rc=$?"
 i=0
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES"; do
   i=$((i+1))
@@ -35,4 +38,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/s
 echo "sgm stats rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $out/sgm_pmc -- python3 $repo/tools/time_sgm.py > /dev/null 2> $out/sgm_pmc.err
 echo "sgm pmc rc=$?"
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/sgm_clk -- python3 $repo/tools/time_sgm.py > /dev/null 2> $out/sgm_clk.err
+echo "sgm clk rc=$?"
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --objects-only > $out/bench_objects_only.json 2> $out/bench_objects_only.err
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 1 > $out/bench_chunks1.json 2> $out/bench_chunks1.err
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 2 > $out/bench_chunks2.json 2> $out/bench_chunks2.err
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 1 --steps 200 --warmup 50 > $out/bench_chunks1_long.json 2> $out/bench_chunks1_long.err
+timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 2 --steps 200 --warmup 50 > $out/bench_chunks2_long.json 2> $out/bench_chunks2_long.err
 ls $out
