@@ -40,9 +40,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_C
 echo "sgm pmc rc=$?"
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/sgm_clk -- python3 $repo/tools/time_sgm.py > /dev/null 2> $out/sgm_clk.err
 echo "sgm clk rc=$?"
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --objects-only > $out/bench_objects_only.json 2> $out/bench_objects_only.err
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 1 > $out/bench_chunks1.json 2> $out/bench_chunks1.err
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 2 > $out/bench_chunks2.json 2> $out/bench_chunks2.err
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 1 --steps 200 --warmup 50 > $out/bench_chunks1_long.json 2> $out/bench_chunks1_long.err
-timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 2 --steps 200 --warmup 50 > $out/bench_chunks2_long.json 2> $out/bench_chunks2_long.err
+timeout -k 10 200 python3 $repo/bench.py --no-cpu-baseline --no-config5 --no-latency --objects-only > $out/bench_objects_only.json 2> $out/bench_objects_only.err
+timeout -k 10 200 python3 $repo/bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 1 > $out/bench_chunks1.json 2> $out/bench_chunks1.err
+timeout -k 10 200 python3 $repo/bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 2 > $out/bench_chunks2.json 2> $out/bench_chunks2.err
+timeout -k 10 200 python3 $repo/bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 1 --steps 200 --warmup 50 > $out/bench_chunks1_long.json 2> $out/bench_chunks1_long.err
+timeout -k 10 200 python3 $repo/bench.py --no-cpu-baseline --no-config5 --no-latency --chunks 2 --steps 200 --warmup 50 > $out/bench_chunks2_long.json 2> $out/bench_chunks2_long.err
 ls $out
