@@ -318,9 +318,10 @@ int  mod_memcpy_d2h(ModContext *ctx, void *host_dst, const void *dev_src, uint64
 #define MOD_STAGE_CCL_TILE    1   /* tile stage: k_ccl_bits<n> + k_ccl_tile_list (k_ccl_tile for n > 10): tile-local
                                      connected components (+ k_dynamic_mask / k_tile_flags for a caller's cloud)  */
 #define MOD_STAGE_CCL_LINK    2   /* k_ccl_link: cross-tile unions                                              */
-#define MOD_STAGE_CCL_MERGE   3   /* k_ccl_merge: root-level flatten + record folding; each frame's last workgroup
-                                     runs the size filter and the reference numbering (a kernel of its own, stage
-                                     "select", until ABI version 1)                                             */
+#define MOD_STAGE_CCL_MERGE   3   /* k_ccl_merge: root-level flatten + record folding, and the size filter with the
+                                     reference numbering: in k_ccl_merge's last workgroup per frame for batches of up
+                                     to 16 frames, as k_select behind it for larger ones (a stage of its own, "select",
+                                     until ABI version 1)                                                        */
 #define MOD_STAGE_FINAL       4   /* k_final: labels plane + member compaction + cluster boxes                  */
 #define MOD_STAGE_MEDIAN      5   /* k_median + k_median_ties: median-velocity member; object ids               */
 #define MOD_STAGE_CLUSTER_GROUP 6 /* the whole cluster stage of a call, first launch to last (stages 1..5 and, in a chunked

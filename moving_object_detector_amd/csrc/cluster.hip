@@ -19,8 +19,9 @@
 //                  are united with LDS atomicMin hooks; interior pixels publish parent[p] = tile root with plain stores, halo
 //                  pixels that were reached leave link requests; one partial statistics record per tile root.
 //   k_ccl_link     requests -> unions between tile roots (device-scope atomicMin hooks), one wave per tile.
-//   k_ccl_merge    every tile root finds its final root, folds its record into it; final roots are listed; the frame's last
-//                  workgroup runs the size filter + ordering by first_edge_key (the reference's numbering), cluster work list.
+//   k_ccl_merge    every tile root finds its final root, folds its record into it; final roots are listed; in a small batch the
+//                  frame's last workgroup goes on to the size filter;
+//   k_select       (large batches: a kernel of its own) size filter + ordering by first_edge_key (the reference's numbering), work list.
 //   k_final        labels plane + per-cluster member lists (||v|| bits, pixel).
 //   k_median       exact selection of the member at size/2 by ||v|| (norms held in registers, LDS histogram rounds);
 //   k_median_ties  replay of libstdc++'s introsort for clusters whose median ties between different vectors; the launch's last
@@ -1102,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_ccl_link(DevCam c, ClArgs a, int tiles_
 // of a row one after the other, all rows and tiles of the wave side by side (each root is a chain of dependent accesses).
 __device__ void select_frame(const DevCam &c, const ClArgs &a, ClusterInfo *tmp, int f, int tid);
 
-template <int TH>
+template <int TH, bool FILTER>
 __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles_per_frame, ClusterInfo *tmp) {
   static_assert(64 % TH == 0, "a wave covers whole tiles");
   constexpr int TPW = 64 / TH;                         // tiles per wave
@@ -1134,12 +1135,15 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
       if (ky != kKeyNone) atomicMin(&rkey[r], ky);
     }
   }
-  // The size filter needs every record of the frame folded: the frame's LAST workgroup to get here runs it (round 5; a kernel of its
-  // own until then — one dependent launch less per call, which is what a small batch is made of).  What it reads of the other
+  // FILTER (small batches): the size filter needs every record of the frame folded — the frame's LAST workgroup to get here runs it
+  // (one dependent launch less per call, which is what a small batch is made of; in a large batch the count below — an atomic and
+  // two barriers in each of 30 k workgroups, most of which have nothing else to do — costs more than the launch: 0.080 -> 0.101 ms
+  // per 512 pairs, so large batches keep the filter as a kernel of its own, k_select).  What it reads of the other
   // workgroups' work went to memory past the XCD's L2 — device-scope atomics (counts, sizes, keys) and device-scope stores (the root
   // list) — and has been acknowledged when the writer's waves pass the barrier below (it drains their memory counters); the last
   // workgroup reads it with device-scope loads.  No fence: a device-scope release is a write-back of the XCD's whole L2, and one per
   // workgroup made this kernel 20x slower (0.017 -> 0.36 ms per 64 pairs, measured).
+  if (!FILTER) return;
   __shared__ int s_last;
   __syncthreads();
   if (threadIdx.x == 0) s_last = (atomicAdd(&a.counters[f * 8 + 2], 1) == (int)gridDim.x - 1) ? 1 : 0;
@@ -1148,6 +1152,9 @@ __global__ __launch_bounds__(256) void k_ccl_merge(DevCam c, ClArgs a, int tiles
   if (threadIdx.x == 0) a.counters[f * 8 + 2] = 0;     // (k_median_ties counts its workgroups in frame 0's slot)
   select_frame(c, a, tmp, f, (int)threadIdx.x);
 }
+
+// removeSmallClusters + the reference's numbering as a kernel of its own (large batches): one workgroup per frame
+__global__ __launch_bounds__(256) void k_select(DevCam c, ClArgs a, ClusterInfo *tmp) { select_frame(c, a, tmp, (int)blockIdx.x, (int)threadIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // One workgroup of 256 threads per frame (the frame's last one in k_ccl_merge): size filter, ordering by first_edge_key, new labels,
@@ -1964,6 +1971,7 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a,
   for (int i = tid; i < frames * 8; i += kTieThreads) a.counters[i] = 0;
 }
 
+constexpr int kFusedFilterFrames = 16;   // batches up to this size run the size filter inside k_ccl_merge (see there)
 constexpr int kTileH = 16, kTileWaves = 4;   // tile = 64 x 16 px, 4 rows per wave (measured best of 8x4, 16x4, 16x8, 32x8)
 
 }  // namespace
@@ -2010,7 +2018,11 @@ void launch_ccl_link(const DevCam &c, const ClArgs &a, int frames, hipStream_t s
 void launch_ccl_merge(const DevCam &c, const ClArgs &a, int frames, ClusterInfo *rank_scratch, hipStream_t s) {
   const dim3 g = tile_grid(c, frames);
   const int tiles = (int)(g.x * g.y), per_block = 4 * (64 / kTileH);
-  hipLaunchKernelGGL(k_ccl_merge<kTileH>, dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles, rank_scratch);
+  if (frames <= kFusedFilterFrames) hipLaunchKernelGGL((k_ccl_merge<kTileH, true>), dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles, rank_scratch);
+  else {
+    hipLaunchKernelGGL((k_ccl_merge<kTileH, false>), dim3((tiles + per_block - 1) / per_block, frames), dim3(256), 0, s, c, a, tiles, rank_scratch);
+    hipLaunchKernelGGL(k_select, dim3(frames), dim3(256), 0, s, c, a, rank_scratch);
+  }
 }
 void launch_final(const DevCam &c, const ClArgs &a, int frames, hipStream_t s) {
   // two waves per tile (8 rows each): 1 / 2 / 4 / 8 waves measured 1.419 (176 VGPRs: 2 waves per SIMD) / 0.965 / 1.001 / 1.460 ms per 512
