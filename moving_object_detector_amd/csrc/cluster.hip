@@ -28,6 +28,7 @@
 //                  workgroup assigns the object ids over the accepted clusters and zeroes the counters for the next call.
 #include "mod_launch.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <string>
 #include "introsort_emul.h"
@@ -1655,7 +1656,16 @@ struct TieShared {           // control block of one workgroup of k_median_ties
   int cntA[kTieThreads / 64], cntB[kTieThreads / 64];
   int first, last, depth, m, totA, done;
   uint32_t answer, pivot;
+#ifdef MOD_PHASE_COUNTERS
+  unsigned long long sec[3][8];   // shader cycles per section of a partition step: [HBM arrays / LDS arrays, range > 2048 / LDS, range <= 2048][section]; [..][7] = steps
+  int mode;
+#endif
 };
+#ifdef MOD_PHASE_COUNTERS
+#define TIE_SEC(i) { if (tid == 0) { const unsigned long long t_ = clock64(); sh.sec[grp][i] += t_ - tsec; tsec = t_; } }
+#else
+#define TIE_SEC(i)
+#endif
 
 // One __unguarded_partition_pivot step on [first, last) of (key, val), by the whole workgroup; updates sh.first / sh.last
 // to the side that holds `want`.  Works on HBM or LDS arrays alike (KP is deduced per call site, so each instance keeps its
@@ -1666,6 +1676,15 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
   using namespace introsort_emul;
   const int lane = tid & 63, wv = tid >> 6;
   constexpr int NW = kTieThreads / 64;
+  // elements a wave takes per loop trip, in units of 64: eight reads in flight on HBM arrays (a trip is a memory round trip); ONE on
+  // LDS arrays — there a step is bound by the CU's vector issue (16 waves x the unrolled body: the position pass alone took 4-7 k
+  // cycles whatever the range), and a wave whose slice is 128 elements must not execute the body of 512 (round 5, section clocks)
+  constexpr int U = std::is_same<PP, uint16_t *>::value ? 1 : 8;
+#ifdef MOD_PHASE_COUNTERS
+  const int grp = sh.mode == 0 ? 0 : (last - first > 2048 ? 1 : 2);
+  unsigned long long tsec = clock64();
+  if (tid == 0) sh.sec[grp][7] += 1;
+#endif
   if (tid == 0) {
     sh.depth--;
     // __move_median_to_first(first, first + 1, mid, last - 1): the three keys are fetched together (one memory round trip
@@ -1682,6 +1701,7 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
     sh.pivot = km;
   }
   __syncthreads();
+  TIE_SEC(0)
   const uint32_t pk = sh.pivot;
   // A: elements NOT before the pivot (key <= pk), ranked from the left; B: elements NOT after it (key >= pk), ranked from the
   // right.  Wave w owns one contiguous slice and reads it 64 consecutive elements at a time (4 reads in flight).
@@ -1689,12 +1709,12 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
   const int slice = (((L + NW - 1) / NW) + 63) & ~63;          // a multiple of 64: a wave's 64-element reads never straddle slices
   const int w0 = min(lo + wv * slice, last), w1 = min(w0 + slice, last);
   int cntA = 0, cntB = 0;
-  for (int j0 = w0; j0 < w1; j0 += 512) {
-    uint32_t k4[8];
+  for (int j0 = w0; j0 < w1; j0 += 64 * U) {
+    uint32_t k4[U];
 #pragma unroll
-    for (int u = 0; u < 8; u++) { const int j = j0 + u * 64 + lane; k4[u] = (j < w1) ? key[j] : 0u; }
+    for (int u = 0; u < U; u++) { const int j = j0 + u * 64 + lane; k4[u] = (j < w1) ? key[j] : 0u; }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < U; u++) {
       const bool in = j0 + u * 64 + lane < w1;
       cntA += __popcll((unsigned long long)__ballot(in && k4[u] <= pk));
       cntB += __popcll((unsigned long long)__ballot(in && k4[u] >= pk));
@@ -1702,6 +1722,7 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
   }
   if (lane == 0) { sh.cntA[wv] = cntA; sh.cntB[wv] = cntB; }
   __syncthreads();
+  TIE_SEC(1)
   if (tid == 0) {
     int run = 0;
     for (int t = 0; t < NW; t++) { const int x = sh.cntA[t]; sh.cntA[t] = run; run += x; }
@@ -1710,16 +1731,17 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
     sh.m = 0;
   }
   __syncthreads();
+  TIE_SEC(2)
   {
     int runA = sh.cntA[wv], seenB = 0, mloc = 0;
     const int sufB = sh.cntB[wv];
     const uint64_t lt = (1ull << lane) - 1ull, le_m = lt | (1ull << lane);
-    for (int j0 = w0; j0 < w1; j0 += 512) {
-      uint32_t k4[8];
+    for (int j0 = w0; j0 < w1; j0 += 64 * U) {
+      uint32_t k4[U];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int j = j0 + u * 64 + lane; k4[u] = (j < w1) ? key[j] : 0u; }
+      for (int u = 0; u < U; u++) { const int j = j0 + u * 64 + lane; k4[u] = (j < w1) ? key[j] : 0u; }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < U; u++) {
         const int j = j0 + u * 64 + lane;
         const bool in = j < w1, le = in && k4[u] <= pk, ge = in && k4[u] >= pk;
         const uint64_t bl = __ballot(le), bg = __ballot(ge);
@@ -1727,15 +1749,17 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
         // elements of B strictly right of j: later waves' + this wave's not yet seen, minus those up to and including this lane
         const int geR = sufB + (cntB - seenB - __popcll((unsigned long long)(bg & le_m)));
         // the iA-th stop of the left pointer swaps iff the iA-th stop of the right pointer lies right of it
-        if (le) { Apos[iA] = j; mloc += (geR >= iA + 1); }
+        if (le) Apos[iA] = j;
+        mloc += __popcll((unsigned long long)__ballot(le && geR >= iA + 1));   // (wave-uniform: one LDS atomic per wave below, not one per lane — 1024 adds on one address serialise)
         if (ge) Bpos[geR] = j;
         runA += __popcll((unsigned long long)bl);
         seenB += __popcll((unsigned long long)bg);
       }
     }
-    if (mloc) atomicAdd(&sh.m, mloc);
+    if (mloc && lane == 0) atomicAdd(&sh.m, mloc);
   }
   __syncthreads();
+  TIE_SEC(3)
   const int m = sh.m;
   for (int i0 = tid; i0 < m; i0 += kTieThreads * 2) {           // the m swaps, two per thread in flight
     const int i1 = i0 + kTieThreads;
@@ -1747,6 +1771,7 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
     if (i1 < m) { key[a1] = kb1; val[a1] = vb1; key[b1] = ka1; val[b1] = va1; }
   }
   __syncthreads();
+  TIE_SEC(4)
   if (tid == 0) {
     // the left pointer's final stop: the next untouched element of A, unless the right pointer's last swap partner comes first
     const int am = (m < sh.totA) ? (int)Apos[m] : 0x7fffffff, bm = (m > 0) ? (int)Bpos[m - 1] : 0x7fffffff;
@@ -1754,6 +1779,7 @@ __device__ __forceinline__ void tie_partition_step(KP key, KP val, PP Apos, PP B
     if (want >= cut) sh.first = cut; else sh.last = cut;
   }
   __syncthreads();
+  TIE_SEC(5)
 }
 
 // Runs partition steps until the live range is at most `stop` elements long (or the depth limit turns it into a heap sort).
@@ -1928,6 +1954,10 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a,
     __syncthreads();
     // ---- introsort, only along the range that holds position size/2: in HBM while the range is long, then in LDS ----
     const int want = size / 2;
+#ifdef MOD_PHASE_COUNTERS
+    if (tid == 0) { sh.mode = 0; for (int g = 0; g < 3; g++) for (int i = 0; i < 8; i++) sh.sec[g][i] = 0; }
+    __syncthreads();
+#endif
     tie_narrow(key, val, Apos, Bpos, want, kTieLds, sh, tid);
     TSTAMP(24)
     if (MOD_ABLATE(c, 1 << 23)) continue;
@@ -1937,6 +1967,9 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a,
       for (int i = tid; i < len; i += kTieThreads) { lkey[i] = key[first + i]; lval[i] = val[first + i]; }
       __syncthreads();
       if (tid == 0) { sh.first = 0; sh.last = len; }
+#ifdef MOD_PHASE_COUNTERS
+      if (tid == 0) sh.mode = 1;
+#endif
       __syncthreads();
       tie_narrow(lkey, lval, lA, lB, want - first, 16, sh, tid);
       __syncthreads();
@@ -1948,6 +1981,9 @@ __global__ __launch_bounds__(kTieThreads) void k_median_ties(DevCam c, ClArgs a,
       __syncthreads();
     }
     TSTAMP(25)
+#ifdef MOD_PHASE_COUNTERS
+    if (tid == 0) for (int g = 0; g < 3; g++) for (int i = 0; i < 8; i++) atomicAdd(&a.dbg[(g == 0 ? 0 : g == 1 ? 8 : 44) + i], sh.sec[g][i]);   // (slots 0-15 are k_ccl_tile's, unused with the bit-plane tile stage at n = 4)
+#endif
     if (tid == 0) {
       const uint32_t best = sh.answer;
       ci->med_pix = (int)best; ci->ambiguous = 2;    // 2 = tie resolved by replaying the reference's sort

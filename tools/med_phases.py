@@ -30,3 +30,7 @@ print("k_median per cluster-carrying block (100 MHz ticks -> us), summed over bl
 print("  per busy block: round-0 pass %.1f scan %.1f | later rounds pass %.1f scan %.1f | compaction pass %.1f  (us)" % tuple(out[i] / 100.0 / n for i in (30, 31, 32, 33, 34)))
 print("k_median blocks: busy %d, mean busy-block life %.1f us, first start -> last end %.1f us" % (out[41], out[40] / n / 100.0, (out[43] - out[42]) / 100.0))
 print("k_median_ties (us, total over the launch): box %.1f  mask %.1f  place %.1f  (layout total %.1f)  hbm partition %.1f  lds %.1f" % tuple(out[i] / 100.0 for i in (20, 21, 22, 23, 24, 25)))
+for name, base in (("HBM arrays", 0), ("LDS arrays, range > 2048", 8), ("LDS arrays, range <= 2048", 44)):
+    n = max(int(out[base + 7]), 1)
+    print(f"tie partition steps on {name}: {int(out[base + 7])} steps; shader cycles per step and section (pivot, count pass, prefix, position pass, swaps, decision): "
+          + " ".join(f"{out[base + i] / n:.0f}" for i in range(6)))
