@@ -154,3 +154,37 @@ def test_scratch_is_left_clean_across_calls_of_different_shape(oracle):
     ctx.synchronize()
     _same(_outputs(ctx, ws), fresh(7, 14))
     ctx.close()
+
+
+def test_size_filter_inside_the_merge_kernel_and_as_a_kernel_of_its_own_agree():
+    """Batches of up to 16 frames run the size filter in k_ccl_merge's last workgroup per frame, larger ones as k_select behind it
+    (cluster.hip kFusedFilterFrames): 16 and 17 frames of one stream, the fused call and the clusterer alone, against one-frame calls."""
+    from moving_object_detector_amd import synth
+    W, H, F = 320, 240, 17
+    cam, sq = _stream(W, H, F, seed=5)
+    prm = synth.Params(dynamic_flow_diff=1, cluster_size=60)
+    one = _ctx(W, H, 1, cam, prm, 0)
+    w1 = one.workspace(1)
+    single = []
+    for f in range(F):
+        assert one.process(_batch(one, sq, f, f + 1), w1) == 0
+        one.synchronize()
+        single.append(_outputs(one, w1))
+    one.close()
+    assert sum(int(o[2][0]) for o in single) > F // 2
+    for frames in (16, 17):
+        ctx = _ctx(W, H, frames, cam, prm, 0)
+        ws = ctx.workspace(frames)
+        for mode in ("fused", "clusterer alone"):
+            ws["labels"].fill_(-7); ws["objects"].zero_(); ws["n_objects"].fill_(-1); ws["n_clusters"].fill_(-1)
+            if mode == "fused":
+                assert ctx.process(_batch(ctx, sq, 0, frames), ws) == 0
+            else:                                            # the planes of the fused call, clustered again as a caller's cloud
+                assert ctx.cluster(frames, ws, mask_ready=False) == 0
+            ctx.synchronize()
+            got = _outputs(ctx, ws)
+            for f in range(frames):
+                assert np.array_equal(got[1][f], single[f][1][0]), (mode, frames, f)
+                assert got[2][f] == single[f][2][0] and got[3][f] == single[f][3][0], (mode, frames, f)
+                assert got[4][f] == single[f][4][0], (mode, frames, f)
+        ctx.close()
