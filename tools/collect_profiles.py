@@ -14,8 +14,9 @@ three = []
 for d in sorted(glob.glob("gpurun_out/final_stats[0-9]")):
     fs = glob.glob(f"{d}/*/*_kernel_stats.csv")
     if not fs or not os.path.getsize(f"{d}/bench.json"): continue
-    avg = [float(r["AverageNs"]) for r in csv.DictReader(open(fs[0])) if "k_scene_flow" in r["Name"]]
-    if avg: three.append((avg[0], fs[0], f"{d}/bench.json"))
+    newest = max(fs, key=os.path.getmtime)            # gpurun merges into old directories: take this session's file
+    avg = [float(r["AverageNs"]) for r in csv.DictReader(open(newest)) if "k_scene_flow" in r["Name"]]
+    if avg: three.append((avg[0], newest, f"{d}/bench.json"))
 stats_line = f"{src}/stats_bench.json"
 if len(three) == 3:
     three.sort()
