@@ -64,9 +64,7 @@ typedef struct ModConfig {
                            selection, tie replay) share the GPU with the streaming kernels of another chunk; forked from and joined
                            to `stream` with events — the call is ordered on `stream` like any other; a chunk has at least 32 frames.
                            0 or 1 -> one piece (the default).  Results do not depend on it.  Worth 1 - 3 % of a 512-pair step in a
-                           long-running process and nothing in a process's first calls (csrc/mod_sf.hip process_chunked).
-                           Bits 8 and 9 are measurement switches (tools/chunk_ab.py): cut the scene-flow kernel too / hold the
-                           chunks' kernel chains one kernel apart */
+                           long-running process and nothing in a process's first calls (csrc/mod_sf.hip process_chunked). */
   void   *stream;       /* hipStream_t to enqueue on; NULL -> the context creates its own */
 } ModConfig;
 

@@ -105,8 +105,8 @@ struct ModContext {
   // chunks of a large batch (process_chunked): chunk 0 runs on the context's stream, chunk k > 0 on chunk_stream[k - 1], forked from
   // and joined to the context's stream with events, so the call keeps the stream semantics of every other entry point
   hipStream_t chunk_stream[kMaxChunks - 1] = {};
-  hipEvent_t ev_fork = nullptr, ev_step[kMaxChunks] = {}, ev_join[kMaxChunks - 1] = {};
-  // The tile headers (word 0) and the cluster counters are ZERO between calls: mod_create clears them once, and the cluster stage's
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxChunks - 1] = {};
+  // The tile headers (word 0) and the cluster counters are ZERO between calls: the context's first call clears them, and the cluster stage's
   // last readers (k_final; k_median_ties' last workgroup) clear what a call has set — two memsets less in front of every call, which
   // a small batch feels (a launch costs it ~8 us of GPU time whatever it does).  False while a call is being enqueued; a call that
   // failed half-way leaves it false and the next one clears the scratch itself.
@@ -253,7 +253,7 @@ void fill_frame_const(FrameConst &h, const ModTransform &tf, double dt) {
 }
 
 // The per-frame constants of a batch.  Up to MOD_SF_INLINE_FRAMES frames: into `inl`, which the scene-flow launch passes in its
-// kernel arguments (returns true) — nothing is copied, nothing waited for.  Larger batches: through the pinned ring into c->b.fc.
+// kernel arguments (inl->used) — nothing is copied, nothing waited for.  Larger batches: through the pinned ring into c->b.fc.
 struct InlineConsts { FrameConst v[MOD_SF_INLINE_FRAMES]; bool used = false; };
 
 int upload_frame_consts(ModContext *c, const ModFrameBatch *in, InlineConsts *inl) {
@@ -350,10 +350,9 @@ int check_cluster_io(ModContext *c, const ModSceneFlowPlanes *pl, bool flags_rea
   return MOD_OK;
 }
 
-// The clustering of one chunk on stream s.  `after_tile_stage` (optional) is recorded behind the chunk's tile stage: the next
-// chunk's tile stage waits for it (process_chunked).
+// The clustering of one chunk on stream s.
 int enqueue_cluster(ModContext *c, Chunk ch, const ModSceneFlowPlanes *pl, const uint64_t *mask, bool mask_ready, bool flags_ready,
-                    const ModClusterOut *out, hipStream_t s, hipEvent_t after_tile_stage) {
+                    const ModClusterOut *out, hipStream_t s) {
   const size_t N = (size_t)c->dc.W * c->dc.H, f0 = (size_t)ch.f0, MWH = (size_t)c->dc.mask_words * c->dc.H, MO = (size_t)c->max_objects;
   const size_t tiles = (size_t)c->dc.mask_words * ((c->dc.H + ccl_tile_rows() - 1) / ccl_tile_rows());
   const int frames = ch.n;
@@ -379,7 +378,6 @@ int enqueue_cluster(ModContext *c, Chunk ch, const ModSceneFlowPlanes *pl, const
     if (!flags_ready) launch_tile_flags(c->dc, a, frames, s);
     launch_ccl_tile(c->dc, a, frames, s);                 // (the counters are zero: ModContext::scratch_clean)
   }
-  if (after_tile_stage) HIP_TRY(c, hipEventRecord(after_tile_stage, s));
   { StageTimer t(c, MOD_STAGE_CCL_LINK, s); launch_ccl_link(c->dc, a, frames, s); }
   { StageTimer t(c, MOD_STAGE_CCL_MERGE, s); launch_ccl_merge(c->dc, a, frames, rank_scratch, s); }
   { StageTimer t(c, MOD_STAGE_FINAL, s); launch_final(c->dc, a, frames, s); }
@@ -392,7 +390,7 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
   int rc = check_cluster_io(c, pl, flags_ready, out);
   if (rc) return rc;
   StageTimer t(c, MOD_STAGE_CLUSTER_GROUP, c->stream);
-  if ((rc = enqueue_cluster(c, Chunk{0, frames}, pl, mask, mask_ready, flags_ready, out, c->stream, nullptr))) return rc;
+  if ((rc = enqueue_cluster(c, Chunk{0, frames}, pl, mask, mask_ready, flags_ready, out, c->stream))) return rc;
   HIP_TRY(c, hipGetLastError());
   return MOD_OK;
 }
@@ -400,7 +398,6 @@ int run_cluster(ModContext *c, int frames, const ModSceneFlowPlanes *pl, const u
 int ensure_chunk_streams(ModContext *c) {
   if (c->ev_fork) return MOD_OK;
   for (hipStream_t &q : c->chunk_stream) if (!q) HIP_TRY(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
-  for (hipEvent_t &e : c->ev_step) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (hipEvent_t &e : c->ev_join) if (!e) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   // a few fork / join rounds, once: the runtime builds the cross-stream signalling of the new streams here, not inside the first call
@@ -418,7 +415,7 @@ int ensure_chunk_streams(ModContext *c) {
 // How many chunks a fused call of `frames` frames runs in (ModConfig.batch_chunks; mod_sf.h).  One chunk while a per-kernel
 // cluster timer is on: the kernels of different chunks run side by side, and a timer would price its kernel with its neighbours' load.
 int chunk_count(const ModContext *c, int frames) {
-  const int want = c->cfg.batch_chunks & 0xff;
+  const int want = c->cfg.batch_chunks;
   const int per_kernel = ((1 << MOD_STAGE_CCL_TILE) | (1 << MOD_STAGE_CCL_LINK) | (1 << MOD_STAGE_CCL_MERGE) | (1 << MOD_STAGE_FINAL) |
                           (1 << MOD_STAGE_MEDIAN));
   if (c->profiling & per_kernel) return 1;
@@ -437,28 +434,22 @@ int chunk_count(const ModContext *c, int frames) {
 // A/B on four boxes: tools/chunk_ab.py, tools/step_trace.py; bench.py --steps 200 --warmup 50: 5.11 - 5.18 vs 5.23 ms); in the first
 // ~25 calls of a fresh process they ADD 2 % (bench.py --steps 20 --warmup 5: 5.28 - 5.31 vs 5.15 - 5.21 ms) — the first calls show
 // hitches of ~0.9 ms each (the host falls behind while the runtime grows what the new streams need; a burst of fills and fork /
-// join rounds at stream creation did not remove them).  Hence not the default.  Chains held one kernel apart by events (bit 9):
-// no better than free-running ones; 3 or 4 chunks like 2.  The scene-flow kernel stays ONE launch over the whole batch ahead of
-// the chunks: it is bandwidth-bound throughout and gains nothing from company (bit 8 cuts it too: +0.5 ... +3 %, and its own time
-// can then no longer be told from its neighbours').
+// join rounds at stream creation did not remove them).  Hence not the default.  Also measured with switches that have left the
+// code again (commit d9702f0 of round 5 has them: ModConfig.batch_chunks bits 8 and 9): chains held one kernel apart by events — no better than free-running ones; 3 or
+// 4 chunks like 2; the scene-flow kernel cut into the chunks too — +0.5 ... +3 % (it is bandwidth-bound throughout and gains
+// nothing from company), so it stays ONE launch over the whole batch ahead of the chunks.
 int process_chunked(ModContext *c, const ModFrameBatch *in, const ModSceneFlowPlanes *pl, uint64_t *mask, const ModClusterOut *out, int C) {
-  const bool sf_chunked = (c->cfg.batch_chunks & 0x100) != 0, free_running = (c->cfg.batch_chunks & 0x200) == 0;
   int rc = ensure_chunk_streams(c);
   if (rc) return rc;
   if ((rc = upload_frame_consts(c, in, nullptr))) return rc;
-  if (!sf_chunked) enqueue_scene_flow(c, in, pl, mask, true, Chunk{0, in->frames}, c->stream);
+  enqueue_scene_flow(c, in, pl, mask, true, Chunk{0, in->frames}, c->stream);
   StageTimer group(c, MOD_STAGE_CLUSTER_GROUP, c->stream);
   HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
   for (int k = 0; k < C; k++) {
     const Chunk ch{(int)((int64_t)in->frames * k / C), (int)((int64_t)in->frames * (k + 1) / C - (int64_t)in->frames * k / C)};
     hipStream_t s = k ? c->chunk_stream[k - 1] : c->stream;
     if (k) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fork, 0));
-    if (k && !free_running) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_step[k - 1], 0));
-    if (sf_chunked) {
-      enqueue_scene_flow(c, in, pl, mask, true, ch, s);
-      HIP_TRY(c, hipEventRecord(c->ev_step[k], s));
-    }
-    if ((rc = enqueue_cluster(c, ch, pl, mask, true, true, out, s, sf_chunked ? nullptr : c->ev_step[k]))) return rc;
+    if ((rc = enqueue_cluster(c, ch, pl, mask, true, true, out, s))) return rc;
     if (k) HIP_TRY(c, hipEventRecord(c->ev_join[k - 1], s));
   }
   for (int k = 1; k < C; k++) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[k - 1], 0));
@@ -483,7 +474,7 @@ int mod_create(const ModConfig *cfg, ModContext **out_ctx) {
   // launch geometry and index widths: frames ride in grid.y / grid.z (<= 65535), the scene-flow kernel addresses a frame's
   // planes with 32-bit byte offsets (32 B/px for the AoS cloud), cluster work items are frame * max_objects + cluster in 32 bits
   if (cfg->max_frames > 65535 || cfg->max_width > MOD_MAX_WIDTH) return MOD_ERR_INVALID_ARGUMENT;
-  if (cfg->batch_chunks < 0 || (cfg->batch_chunks & 0xff) > kMaxChunks || (cfg->batch_chunks & ~0x3ff)) return MOD_ERR_INVALID_ARGUMENT;
+  if (cfg->batch_chunks < 0 || cfg->batch_chunks > kMaxChunks) return MOD_ERR_INVALID_ARGUMENT;
   if ((uint64_t)cfg->max_width * (uint64_t)cfg->max_height >= (1ull << 27)) return MOD_ERR_INVALID_ARGUMENT;
   if (cfg->max_objects > 0 && (uint64_t)cfg->max_objects * (uint64_t)cfg->max_frames >= (1ull << 31)) return MOD_ERR_INVALID_ARGUMENT;
   int ndev = 0;
@@ -569,7 +560,6 @@ void mod_destroy(ModContext *c) {
     for (hipEvent_t e : c->b.sgm_join[k]) if (e) (void)hipEventDestroy(e);
   }
   for (hipStream_t q : c->chunk_stream) if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-  for (hipEvent_t e : c->ev_step) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->ev_join) if (e) (void)hipEventDestroy(e);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

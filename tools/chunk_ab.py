@@ -1,7 +1,9 @@
 """mod_process_dev in chunks (ModConfig.batch_chunks), A/B INSIDE one process: the same input and output buffers, one context per
 setting, taken in turns.  Checks that every setting gives the un-chunked call's labels and objects, then times the whole step (wall
 clock), the scene-flow kernel and the cluster group (stage timers 0 and 7).
-python tools/chunk_ab.py [setting ...]   setting = chunks | 0x100 (scene-flow kernel cut too) | 0x200 (chunks held one kernel apart)"""
+python tools/chunk_ab.py [chunks ...]   (the round's logs under profiles/r05_logs/ also hold settings | 0x100 (scene-flow kernel cut too) and
+| 0x200 (no step order / chunks held one kernel apart, depending on the build): measurement switches of commits 557698a ... d9702f0 that
+have left the library again)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +12,7 @@ from moving_object_detector_amd import capi, synth
 from moving_object_detector_amd import pipeline
 
 W, H, F, G = 1280, 720, int(os.environ.get("FRAMES", 512)), 16
-settings = [int(a, 0) for a in sys.argv[1:]] or [1, 2, 3, 4, 0x102, 0x202]
+settings = [int(a, 0) for a in sys.argv[1:]] or [1, 2, 3, 4]
 cam, sq = synth.make_sequence(W, H, G, seed=4)
 idx = [i % G for i in range(F)]
 dev = torch.device("cuda:0")
