@@ -418,6 +418,8 @@ def run():
         if group_up:
             dist.barrier()
 
+    # the warm-up steps run exactly as the timed ones do: same stage timers on (a call's path depends on them: ModConfig.batch_chunks)
+    ctx.set_profiling(True, stages=[capi.MOD_STAGE_SCENE_FLOW, capi.MOD_STAGE_CLUSTER_GROUP])
     for _ in range(args.warmup):
         ctx.process(batch, ws)
     torch.cuda.synchronize()
