@@ -211,8 +211,14 @@ def config5_leg(dev, local_rank):
             # round 3) = 21 per line step, 4 cycles each, over 1024 SIMDs at 2.4 GHz
             valu_ms = PATHS * n * 21 * 4 / (1024 * 2.4e9) * 1e3
             out["sgm_ms_per_frame"] = sgm_frame_ms
+            # the clock the chip HOLDS inside the path grid after seconds of back-to-back calls (in-kernel s_memtime / s_memrealtime
+            # stamps of a diagnostic build, tools/sgm_clock_probe.py, round 5; GRBM_GUI_ACTIVE in the counter passes: 2.10-2.12)
+            SGM_CLOCK_GHZ = 2.157
             out["sgm_roofline"] = {"bytes_per_px": 2 * PATHS * D, "GBps": gbs, "frac": gbs / HBM_PEAK_GBS, "valu_bound_ms": valu_ms,
-                                   "frac_of_valu_bound": valu_ms / sgm_frame_ms, "at": "1280x720, 16 frames per step = two groups of 8, pipelined",
+                                   "frac_of_valu_bound": valu_ms / sgm_frame_ms,
+                                   "clock_held_ghz_measured_round5": SGM_CLOCK_GHZ,
+                                   "frac_of_valu_bound_at_clock_held": valu_ms * 2.4 / SGM_CLOCK_GHZ / sgm_frame_ms,
+                                   "at": "1280x720, 16 frames per step = two groups of 8, pipelined",
                                    "one_group_ms_per_frame": out.get("sgm_ms_per_frame_720_one_group")}
             check = (imgs[0][0], imgs[0][1], D, d_now[0].cpu().numpy())
         ctx.close()
