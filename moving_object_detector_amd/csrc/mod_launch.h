@@ -60,6 +60,8 @@ void launch_scene_flow(const DevCam &c, const SfArgs &a, int frames, const Frame
 void launch_dynamic_mask(const DevCam &c, int frames, const float *vx, const float *vy, const float *vz, uint64_t *mask,
                          hipStream_t s);
 void launch_depth(const DevCam &c, int frames, const float *dnow, float *depth, hipStream_t s);
+// n 8-byte words from (device-visible, e.g. pinned host) src to dst
+void launch_copy_words(const unsigned long long *src, unsigned long long *dst, size_t n, hipStream_t s);
 void launch_pack(size_t n, const float *x, const float *y, const float *z, const float *vx, const float *vy, const float *vz,
                  void *aos, hipStream_t s);
 void launch_unpack(size_t n, const void *aos, float *x, float *y, float *z, float *vx, float *vy, float *vz, hipStream_t s);

@@ -267,7 +267,10 @@ int upload_frame_consts(ModContext *c, const ModFrameBatch *in, InlineConsts *in
   HIP_TRY(c, hipEventSynchronize(c->pinned_ev[slot]));   // the slot's previous copy has left the host buffer
   FrameConst *h = c->pinned[slot];
   for (int f = 0; f < in->frames; f++) fill_frame_const(h[f], in->transforms[f], in->dt[f]);
-  HIP_TRY(c, hipMemcpyAsync(c->b.fc, h, sizeof(FrameConst) * in->frames, hipMemcpyHostToDevice, c->stream));
+  // a kernel of ours reads the pinned slot over the host link (hipHostMalloc memory is mapped into the device's address space):
+  // the runtime's own host-to-device copy is a blit kernel too, and the kernel behind it started 5 us after it had ended
+  launch_copy_words((const unsigned long long *)h, (unsigned long long *)c->b.fc, sizeof(FrameConst) / 8 * (size_t)in->frames, c->stream);
+  HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(c->pinned_ev[slot], c->stream));
   return MOD_OK;
 }

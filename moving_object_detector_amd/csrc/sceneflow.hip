@@ -19,6 +19,7 @@
 
 #include "exact_div.h"
 #include "mod_launch.h"
+#include <algorithm>
 
 #pragma clang fp contract(off)
 
@@ -592,6 +593,13 @@ void launch_dynamic_mask(const DevCam &c, int frames, const float *vx, const flo
                          hipStream_t s) {
   dim3 block(64, 4, 1), grid((c.W + 63) / 64, (c.H + 3) / 4, frames);
   hipLaunchKernelGGL(k_dynamic_mask, grid, block, 0, s, c, vx, vy, vz, mask);
+}
+
+__global__ __launch_bounds__(256) void k_copy_words(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+void launch_copy_words(const unsigned long long *src, unsigned long long *dst, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n + 255) / 256, 64)), dim3(256), 0, s, src, dst, n);
 }
 
 void launch_depth(const DevCam &c, int frames, const float *dnow, float *depth, hipStream_t s) {
